@@ -1,0 +1,264 @@
+/*
+ * rt_mi355x.h — C ABI of librt_mi355x.so, the MI355X (gfx950) rendering backend that
+ * replaces the per-pixel hot path of mariusdanciu/ray-tracing.
+ *
+ * The reference has no FFI of its own: the seam is Renderer::render (src/renderer.rs:81-151),
+ * whose rayon block (src/renderer.rs:104-143) is what these entry points replace.  Every
+ * struct below is the plain-data mirror of a reference type, every function cites the
+ * reference code whose behaviour it takes over.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative rt_status on failure; the text of
+ *     the last failure of a context is returned by rt_last_error().  Nothing throws or
+ *     aborts across this boundary (reference: Result<(), String>, src/renderer.rs:89).
+ *   - matrices are 16 floats, column-major, exactly glam's Mat4::to_cols_array().
+ *   - a context belongs to one GPU and is driven from one thread at a time
+ *     (reference: render is called from the single SDL main thread, src/app.rs:248).
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef struct rt_ctx rt_ctx;
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1, /* null pointer, bad size, index out of range          */
+    RT_ERR_UNSUPPORTED = -2,      /* legal in the reference but beyond a stated limit    */
+    RT_ERR_DEVICE = -3,           /* a HIP call failed; rt_last_error has the HIP string */
+    RT_ERR_STATE = -4             /* call order: scene/camera not set yet                */
+} rt_status;
+
+/* Object3D variants in declaration order (src/objects.rs:21-30). */
+typedef enum rt_object_kind {
+    RT_SPHERE = 0,
+    RT_TRIANGLE = 1,
+    RT_CUBOID = 2,
+    RT_PLANE = 3,
+    RT_CYLINDER = 4,
+    RT_CONE = 5,
+    RT_UNION = 6,
+    RT_SUBSTRACTION = 7
+} rt_object_kind;
+
+/*
+ * One Object3D.  Only the fields of the object's own kind are read.
+ *   Sphere       src/utils/sphere.rs:15-23     transform, inv_transform, radius
+ *   Triangle     src/utils/triangle.rs:12-17   v1, v2, v3
+ *   Cuboid       src/utils/cuboid.rs:12-21     transform, inv_transform, dimension (b_min/b_max = -/+dimension)
+ *   Plane        src/utils/plane.rs:10-15      normal, point, max_dist (+has_max_dist for Option)
+ *   Cylinder     src/utils/cylinder.rs:14-22   transform, inv_transform, radius, height
+ *   Cone         src/utils/cone.rs:14-22       transform, inv_transform
+ *   Union        src/utils/union.rs:12-15      first, second
+ *   Substraction src/utils/substraction.rs:12-15 first, second
+ * transform/inv_transform must be the identity for Triangle, Plane, Union and Substraction
+ * (Object3D::transform, src/objects.rs:71-82).  material_index is 0 for Union and
+ * Substraction (src/objects.rs:54-55).  position/rotation_axis are informative: they are
+ * already folded into the matrices by the object's update() on the caller's side.
+ */
+typedef struct rt_object {
+    int32_t kind;
+    int32_t material_index;
+    float transform[16];
+    float inv_transform[16];
+    float position[3];
+    float rotation_axis[3];
+    float radius;
+    float height;
+    float dimension[3];
+    float normal[3];
+    float point[3];
+    float max_dist[2];
+    int32_t has_max_dist;
+    float v1[3];
+    float v2[3];
+    float v3[3];
+    int32_t first;
+    int32_t second;
+} rt_object;
+
+/* MaterialType (src/objects.rs:86-95). */
+typedef enum rt_material_kind { RT_REFLECTIVE = 0, RT_REFRACTIVE = 1 } rt_material_kind;
+
+/* Material (src/objects.rs:151-160); texture = -1 encodes Option::None. */
+typedef struct rt_material {
+    float ambience;
+    float diffuse;
+    float specular;
+    float shininess;
+    float albedo[3];
+    int32_t texture;
+    int32_t kind;
+    float roughness;        /* Reflective */
+    float transparency;     /* Refractive */
+    float refraction_index; /* Refractive */
+    float reflectivity;     /* Refractive */
+    float emission_power;
+} rt_material;
+
+/* Light variants (src/light.rs:29-33). */
+typedef enum rt_light_kind { RT_DIRECTIONAL = 0, RT_POSITIONAL = 1, RT_SPHERICAL_POSITIONAL = 2 } rt_light_kind;
+
+/* Light (src/light.rs:3-20); vec is `direction` for Directional, `position` otherwise. */
+typedef struct rt_light {
+    int32_t kind;
+    float albedo[3];
+    float vec[3];
+    float radius; /* SphericalPositional only; never read by the integrators (src/light.rs:60-75) */
+    float intensity;
+} rt_light;
+
+/* Scene (src/scene.rs:13-29) without textures (rt_set_texture) and update_func (stays host-side). */
+typedef struct rt_scene_desc {
+    const rt_object *objects;
+    const rt_material *materials;
+    const rt_light *lights;
+    const uint32_t *sdfs; /* Scene.sdfs: indices into objects, ray-marching list */
+    uint32_t n_objects;
+    uint32_t n_materials;
+    uint32_t n_lights;
+    uint32_t n_sdfs;
+    uint32_t n_textures; /* number of texture slots Scene.textures holds */
+    float ambient_color[3];
+    uint8_t max_ray_bounces;
+    uint8_t shadow_casting;
+    uint8_t ray_marching;
+    uint8_t diffuse;
+    uint8_t enable_accumulation; /* Scene.enable_accumulation: reflection jitter (src/ray.rs:111-120) */
+    uint8_t reserved[3];
+} rt_scene_desc;
+
+/* The parts of Camera (src/camera.rs:6-20) that calculate_ray_directions (src/camera.rs:128-157) reads. */
+typedef struct rt_camera_desc {
+    uint32_t width;
+    uint32_t height;
+    float position[3];
+    float inverse_perspective[16];
+    float inverse_view[16];
+} rt_camera_desc;
+
+/* Counter slots of rt_stats.counters.  A "ray" is one trace_ray (src/ray_tracing/ray_tracing.rs:59)
+ * or one march_ray (src/ray_marching/ray_marching.rs:181) invocation.  The remaining slots count the
+ * events the algorithmic-FLOP model prices; they are only filled by a render with collect_events=1. */
+typedef enum rt_counter {
+    RT_CNT_RAYS_PRIMARY = 0,
+    RT_CNT_RAYS_REFLECTION,
+    RT_CNT_RAYS_REFRACTION,
+    RT_CNT_RAYS_SHADOW,
+    RT_CNT_RAYS_MARCH,
+    RT_CNT_RAYGEN,          /* camera ray generated (one per pixel)                   */
+    RT_CNT_TEST_SPHERE,     /* candidate tests inside trace_ray, by primitive kind    */
+    RT_CNT_TEST_TRIANGLE,
+    RT_CNT_TEST_CUBOID,
+    RT_CNT_TEST_PLANE,
+    RT_CNT_TEST_CYLINDER,
+    RT_CNT_TEST_CONE,
+    RT_CNT_HIT_SPHERE,      /* closest hits finalised (shaded or shadow-tested), by kind */
+    RT_CNT_HIT_TRIANGLE,
+    RT_CNT_HIT_CUBOID,
+    RT_CNT_HIT_PLANE,
+    RT_CNT_HIT_CYLINDER,
+    RT_CNT_HIT_CONE,
+    RT_CNT_LIGHT_CALL,      /* light() invocations (one gamma powf triple each)        */
+    RT_CNT_LIGHT_SHADE,     /* per light inside light(): blinn_phong + falloff         */
+    RT_CNT_REFLECTION_RAY,  /* Ray::reflection_ray, mirror or jittered                 */
+    RT_CNT_DIFFUSE_RAY,     /* Ray::reflection_ray, diffuse branch                     */
+    RT_CNT_REFRACTION,      /* fresnel + refraction_ray                                */
+    RT_CNT_COMBINE_REFL,    /* reflective combine (src/ray_tracing/ray_tracing.rs:194) */
+    RT_CNT_COMBINE_REFR,    /* refractive combine (:232-235)                           */
+    RT_CNT_TEX_FETCH,       /* Texture::from_uv outside tri-planar                     */
+    RT_CNT_TRIPLANAR,       /* geometry::tri_planar_mapping (3 fetches included)       */
+    RT_CNT_SDF_SPHERE,      /* leaf SDF evaluations by kind                            */
+    RT_CNT_SDF_CUBOID,
+    RT_CNT_SDF_CYLINDER,
+    RT_CNT_SDF_PLANE,
+    RT_CNT_SDF_UNION,
+    RT_CNT_SDF_SUBSTRACTION,
+    RT_CNT_MARCH_STEP,      /* iterations of march_ray's loop that evaluate sdfs()     */
+    RT_CNT_SDFS_CALL,       /* sdfs() invocations (march + normal + occlusion)         */
+    RT_CNT_OCCLUSION_TAP,
+    RT_CNT_MARCH_SHADE,     /* ray-marching hits shaded (fade + occlusion scale)       */
+    RT_CNT_PIXEL_PACK,      /* clamp / accumulate / to_rgba                            */
+    RT_CNT_COUNT
+} rt_counter;
+
+typedef struct rt_stats {
+    uint64_t rays_total;     /* all trace_ray + march_ray invocations of the last render (always filled) */
+    uint64_t counters[RT_CNT_COUNT]; /* per-kind rays and events; zero unless collect_events was set    */
+    double last_kernel_ms;   /* HIP-event time of the last render's kernel(s) on the launch stream */
+    double last_copy_ms;     /* D2H time of the last rt_render (0 for rt_render_device)            */
+    uint64_t frames_rendered;
+} rt_stats;
+
+/* Arguments of one frame.  Mirrors the per-frame state of Renderer (src/renderer.rs:13-18) as
+ * render_chunk consumes it (src/renderer.rs:38-79). */
+typedef struct rt_render_params {
+    uint32_t frame_index;    /* Renderer.frame_index: divisor in accumulation mode, >= 1             */
+    uint32_t row_begin;      /* rows [row_begin, row_end) are rendered; 0,0 means the whole frame     */
+    uint32_t row_end;
+    int32_t accumulate;      /* Renderer.enable_accumulation                                         */
+    int32_t collect_events;  /* 1: also fill the event slots of rt_stats (slower kernel variant)     */
+    int32_t reserved;
+    uint64_t seed;           /* keys the counter-based generator that stands in for ThreadRng        */
+} rt_render_params;
+
+/* Creates a context bound to HIP device `device_id` (one context per GPU; one process per GPU
+ * in multi-GPU runs).  Replaces nothing in the reference: it owns what Renderer::render keeps on
+ * the host (accumulated, src/renderer.rs:14) plus the device copy of Scene/Camera. */
+int32_t rt_create(int32_t device_id, rt_ctx **out);
+void rt_destroy(rt_ctx *ctx);
+
+/* Uploads Scene (src/scene.rs:13-25) as flat device arrays.  Validates what the reference
+ * would panic on (material / texture / object indices out of range, src/ray_tracing/ray_tracing.rs:92,98)
+ * and the limits of this backend: max_ray_bounces <= 32; Union/Substraction nesting depth <= 2. */
+int32_t rt_set_scene(rt_ctx *ctx, const rt_scene_desc *scene);
+
+/* Uploads Scene.textures[index]: tightly packed RGB8, row-major, exactly Texture.bytes
+ * (src/objects.rs:105-111) as produced by ImageUtils::load_image (src/utils/image.rs:13-29). */
+int32_t rt_set_texture(rt_ctx *ctx, uint32_t index, uint32_t width, uint32_t height, const uint8_t *rgb8);
+
+/* Replaces Camera::calculate_ray_directions (src/camera.rs:128-157): the kernels generate the
+ * primary direction of each pixel from these matrices instead of reading a w*h table. */
+int32_t rt_set_camera(rt_ctx *ctx, const rt_camera_desc *camera);
+
+/* Renderer::render's pixel work (src/renderer.rs:104-143) for one frame into a host buffer:
+ * every pixel p = Scene::pixel (src/scene.rs:80-90); accumulate / clamp / to_rgba as
+ * render_chunk (src/renderer.rs:59-75).  out_rgba8 receives width*height*4 bytes (R,G,B,A).
+ * reset_accum=1 zeroes the device accumulator first (src/renderer.rs:93-96).  Synchronous. */
+int32_t rt_render(rt_ctx *ctx, uint32_t frame_index, int32_t accumulate, int32_t reset_accum, uint64_t seed,
+                  uint8_t *out_rgba8, size_t out_len);
+
+/* Same pixel work, device-resident: writes RGBA8 (width*height*4 bytes) to d_rgba8 and the
+ * accumulator (width*height float4, Renderer.accumulated) to d_accum, both device pointers owned
+ * by the caller; either may be NULL to use the context's own buffers.  `stream` is a hipStream_t
+ * (NULL = the context's stream).  Asynchronous: returns after the launch. */
+int32_t rt_render_device(rt_ctx *ctx, const rt_render_params *params, void *d_rgba8, void *d_accum, void *stream);
+
+/* Zeroes the context's accumulator (Renderer::render on `updated`, src/renderer.rs:93-96). */
+int32_t rt_reset_accum(rt_ctx *ctx);
+
+/* Copies Renderer.accumulated (src/renderer.rs:14) back: n = width*height float4 values. */
+int32_t rt_read_accum(rt_ctx *ctx, float *out_vec4, size_t n_vec4);
+
+/* Waits for the context's stream and sums the per-workgroup counters of the last render. */
+int32_t rt_get_stats(rt_ctx *ctx, rt_stats *out);
+
+/* Device pointers of the context's own frame buffers (valid until the next rt_set_camera). */
+void *rt_device_rgba8(rt_ctx *ctx);
+void *rt_device_accum(rt_ctx *ctx);
+
+const char *rt_last_error(rt_ctx *ctx);
+int32_t rt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

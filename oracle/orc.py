@@ -1,0 +1,86 @@
+"""ctypes wrapper of the CPU parity oracle (liborc.so) — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+PARITY UNPINNED: see rt_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class orc_texture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb8", C.c_void_p)]
+
+
+_libs: dict = {}
+
+
+def load(host_libm: bool = False) -> C.CDLL:
+    name = "liborc_hostlibm.so" if host_libm else "liborc.so"
+    if name not in _libs:
+        path = os.path.join(_HERE, name)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is missing: run `make -C oracle`")
+        l = C.CDLL(path)
+        vp = C.c_void_p
+        l.orc_render.argtypes = [vp, vp, vp, C.c_uint32, C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_int32]
+        l.orc_render.restype = C.c_int32
+        l.orc_camera_ray.argtypes = [vp, C.c_uint32, C.c_uint32, vp]; l.orc_camera_ray.restype = None
+        l.orc_camera_matrices.argtypes = [vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
+        l.orc_camera_matrices.restype = None
+        l.orc_object_transform.argtypes = [vp, vp, vp]; l.orc_object_transform.restype = None
+        l.orc_intersect.argtypes = [vp, vp, vp, vp]; l.orc_intersect.restype = C.c_int32
+        l.orc_sdfs.argtypes = [vp, vp, vp, C.c_float, vp]; l.orc_sdfs.restype = C.c_int32
+        l.orc_texture_from_uv.argtypes = [vp, C.c_float, C.c_float, vp]; l.orc_texture_from_uv.restype = None
+        for f in ("orc_powf_det", "orc_powf_host"):
+            getattr(l, f).argtypes = [C.c_float, C.c_float]; getattr(l, f).restype = C.c_float
+        for f in ("orc_atanf_det", "orc_atanf_host"):
+            getattr(l, f).argtypes = [C.c_float]; getattr(l, f).restype = C.c_float
+        l.orc_rng_path_key.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]; l.orc_rng_path_key.restype = C.c_uint32
+        l.orc_rng_child_key.argtypes = [C.c_uint32, C.c_uint32]; l.orc_rng_child_key.restype = C.c_uint32
+        l.orc_rng_uniform.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_float]; l.orc_rng_uniform.restype = C.c_float
+        l.orc_uses_host_libm.argtypes = []; l.orc_uses_host_libm.restype = C.c_int32
+        _libs[name] = l
+    return _libs[name]
+
+
+def texture_array(textures):
+    """(ctypes array of orc_texture, keep-alive list) from a list of (h, w, 3) uint8 arrays."""
+    arr = (orc_texture * max(len(textures), 1))()
+    keep = []
+    for i, t in enumerate(textures):
+        t = np.ascontiguousarray(t, dtype=np.uint8)
+        keep.append(t)
+        arr[i].width = t.shape[1]
+        arr[i].height = t.shape[0]
+        arr[i].rgb8 = t.ctypes.data
+    return arr, keep
+
+
+def render(desc, camera, textures=(), frame_index=1, accumulate=False, seed=0x5EED, rows=None, accum=None, n_threads=1,
+           want_linear=False, want_counters=False, host_libm=False):
+    """One frame of the reference algorithm on the CPU.
+
+    Returns dict(rgba=(h,w,4) u8, accum=(h,w,4) f32, linear=(h,w,4) f32 or None, counters=list or None).
+    `desc` / `camera` are the ctypes structs of ray_tracing_amd (rt_scene_desc / rt_camera_desc).
+    """
+    l = load(host_libm)
+    w, h = camera.width, camera.height
+    if accum is None:
+        accum = np.zeros((h, w, 4), dtype=np.float32)
+    rgba = np.zeros((h, w, 4), dtype=np.uint8)
+    linear = np.zeros((h, w, 4), dtype=np.float32) if want_linear else None
+    counters = (C.c_uint64 * 64)() if want_counters else None
+    tex, keep = texture_array(list(textures))
+    rb, re = rows if rows is not None else (0, 0)
+    st = l.orc_render(C.addressof(desc), C.addressof(tex), C.addressof(camera), frame_index, int(accumulate), seed, rb, re,
+                      accum.ctypes.data, rgba.ctypes.data, linear.ctypes.data if want_linear else None,
+                      C.addressof(counters) if want_counters else None, n_threads)
+    if st != 0:
+        raise ValueError("orc_render rejected the scene (index out of range / missing texture)")
+    return dict(rgba=rgba, accum=accum, linear=linear, counters=list(counters) if want_counters else None)

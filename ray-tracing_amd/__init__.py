@@ -1,0 +1,363 @@
+"""ctypes bindings of the MI355X rendering backend for mariusdanciu/ray-tracing.
+
+The directory name carries a hyphen, so the package is loaded under the importable name
+``ray_tracing_amd`` by ``__graft_entry__.load_package()`` (tests and bench.py do the same).
+
+Two shared libraries, both built in-tree by ``csrc/Makefile``:
+
+* ``librt_mi355x.so`` — HIP kernels + the C ABI declared in ``include/rt_mi355x.h``.
+* ``librt_host.so``   — C++ mirror of the reference's ``Scene`` / ``Camera`` / ``Renderer`` API
+  (``host/rt_host.h``) with a small C view used here to build the reference's demo scenes.
+
+Nothing in this package falls back to a CPU path: if the HIP library is missing, or no GPU is
+present, the calls fail loudly.  The CPU oracle under ``oracle/`` is test infrastructure and is
+never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+
+# --------------------------------------------------------------------------------------------
+# plain-data mirrors of include/rt_mi355x.h
+# --------------------------------------------------------------------------------------------
+RT_SPHERE, RT_TRIANGLE, RT_CUBOID, RT_PLANE, RT_CYLINDER, RT_CONE, RT_UNION, RT_SUBSTRACTION = range(8)
+RT_REFLECTIVE, RT_REFRACTIVE = 0, 1
+RT_DIRECTIONAL, RT_POSITIONAL, RT_SPHERICAL_POSITIONAL = 0, 1, 2
+
+COUNTER_NAMES = [
+    "rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "rays_march", "raygen",
+    "test_sphere", "test_triangle", "test_cuboid", "test_plane", "test_cylinder", "test_cone",
+    "hit_sphere", "hit_triangle", "hit_cuboid", "hit_plane", "hit_cylinder", "hit_cone",
+    "light_call", "light_shade", "reflection_ray", "diffuse_ray", "refraction", "combine_refl", "combine_refr",
+    "tex_fetch", "triplanar", "sdf_sphere", "sdf_cuboid", "sdf_cylinder", "sdf_plane", "sdf_union", "sdf_substraction",
+    "march_step", "sdfs_call", "occlusion_tap", "march_shade", "pixel_pack",
+]
+RT_CNT_COUNT = len(COUNTER_NAMES)
+
+# Algorithmic FLOPs per counted event: the reference's own arithmetic, 1 per add/mul/div/sqrt/min/max/
+# transcendental, minimal 3x3(+t) form for matrix-vector products (direction 15, point 18).
+EVENT_FLOPS = {
+    "raygen": 65,
+    "test_sphere": 54, "hit_sphere": 51,
+    "test_plane": 14, "hit_plane": 16,
+    "test_cuboid": 58, "hit_cuboid": 61,
+    "test_cylinder": 82, "hit_cylinder": 24,
+    "test_cone": 77, "hit_cone": 27,
+    "test_triangle": 92, "hit_triangle": 47,
+    "light_call": 3, "light_shade": 90,
+    "reflection_ray": 31, "diffuse_ray": 19, "refraction": 50,
+    "combine_refl": 16, "combine_refr": 13,
+    "tex_fetch": 14, "triplanar": 62,
+    "sdf_sphere": 47, "sdf_cuboid": 61, "sdf_cylinder": 57, "sdf_plane": 14, "sdf_union": 22, "sdf_substraction": 2,
+    "march_step": 3, "occlusion_tap": 6, "march_shade": 9, "pixel_pack": 15,
+}
+
+
+def algorithmic_flops(counters: dict) -> int:
+    """Sum of event counts times the per-event FLOP constants."""
+    return int(sum(int(counters.get(k, 0)) * v for k, v in EVENT_FLOPS.items()))
+
+
+class rt_object(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("material_index", C.c_int32),
+        ("transform", C.c_float * 16), ("inv_transform", C.c_float * 16),
+        ("position", C.c_float * 3), ("rotation_axis", C.c_float * 3),
+        ("radius", C.c_float), ("height", C.c_float), ("dimension", C.c_float * 3),
+        ("normal", C.c_float * 3), ("point", C.c_float * 3), ("max_dist", C.c_float * 2), ("has_max_dist", C.c_int32),
+        ("v1", C.c_float * 3), ("v2", C.c_float * 3), ("v3", C.c_float * 3),
+        ("first", C.c_int32), ("second", C.c_int32),
+    ]
+
+
+class rt_material(C.Structure):
+    _fields_ = [
+        ("ambience", C.c_float), ("diffuse", C.c_float), ("specular", C.c_float), ("shininess", C.c_float),
+        ("albedo", C.c_float * 3), ("texture", C.c_int32), ("kind", C.c_int32), ("roughness", C.c_float),
+        ("transparency", C.c_float), ("refraction_index", C.c_float), ("reflectivity", C.c_float),
+        ("emission_power", C.c_float),
+    ]
+
+
+class rt_light(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("albedo", C.c_float * 3), ("vec", C.c_float * 3), ("radius", C.c_float),
+                ("intensity", C.c_float)]
+
+
+class rt_scene_desc(C.Structure):
+    _fields_ = [
+        ("objects", C.POINTER(rt_object)), ("materials", C.POINTER(rt_material)), ("lights", C.POINTER(rt_light)),
+        ("sdfs", C.POINTER(C.c_uint32)),
+        ("n_objects", C.c_uint32), ("n_materials", C.c_uint32), ("n_lights", C.c_uint32), ("n_sdfs", C.c_uint32),
+        ("n_textures", C.c_uint32), ("ambient_color", C.c_float * 3),
+        ("max_ray_bounces", C.c_uint8), ("shadow_casting", C.c_uint8), ("ray_marching", C.c_uint8), ("diffuse", C.c_uint8),
+        ("enable_accumulation", C.c_uint8), ("reserved", C.c_uint8 * 3),
+    ]
+
+
+class rt_camera_desc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("position", C.c_float * 3),
+                ("inverse_perspective", C.c_float * 16), ("inverse_view", C.c_float * 16)]
+
+
+class rt_stats(C.Structure):
+    _fields_ = [("rays_total", C.c_uint64), ("counters", C.c_uint64 * RT_CNT_COUNT), ("last_kernel_ms", C.c_double),
+                ("last_copy_ms", C.c_double), ("frames_rendered", C.c_uint64)]
+
+
+class rt_render_params(C.Structure):
+    _fields_ = [("frame_index", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("accumulate", C.c_int32),
+                ("collect_events", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64)]
+
+
+# every symbol include/rt_mi355x.h declares
+ABI_SYMBOLS = [
+    "rt_create", "rt_destroy", "rt_set_scene", "rt_set_texture", "rt_set_camera", "rt_render", "rt_render_device",
+    "rt_reset_accum", "rt_read_accum", "rt_get_stats", "rt_device_rgba8", "rt_device_accum", "rt_last_error",
+    "rt_abi_version",
+]
+
+LIB_PATH = os.path.join(_HERE, "librt_mi355x.so")
+HOST_LIB_PATH = os.path.join(_HERE, "librt_host.so")
+
+_lib = None
+_host = None
+
+
+class BackendError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+
+def lib() -> C.CDLL:
+    """Loads librt_mi355x.so (raises if it was not built: there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is missing: build it with `make -C ray-tracing_amd/csrc` "
+                                    "(or __graft_entry__.build()); this backend has no CPU fallback")
+        l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        vp = C.c_void_p
+        l.rt_create.argtypes = [C.c_int32, C.POINTER(vp)]; l.rt_create.restype = C.c_int32
+        l.rt_destroy.argtypes = [vp]; l.rt_destroy.restype = None
+        l.rt_set_scene.argtypes = [vp, C.POINTER(rt_scene_desc)]; l.rt_set_scene.restype = C.c_int32
+        l.rt_set_texture.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]; l.rt_set_texture.restype = C.c_int32
+        l.rt_set_camera.argtypes = [vp, C.POINTER(rt_camera_desc)]; l.rt_set_camera.restype = C.c_int32
+        l.rt_render.argtypes = [vp, C.c_uint32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_size_t]; l.rt_render.restype = C.c_int32
+        l.rt_render_device.argtypes = [vp, C.POINTER(rt_render_params), vp, vp, vp]; l.rt_render_device.restype = C.c_int32
+        l.rt_reset_accum.argtypes = [vp]; l.rt_reset_accum.restype = C.c_int32
+        l.rt_read_accum.argtypes = [vp, C.c_void_p, C.c_size_t]; l.rt_read_accum.restype = C.c_int32
+        l.rt_get_stats.argtypes = [vp, C.POINTER(rt_stats)]; l.rt_get_stats.restype = C.c_int32
+        l.rt_device_rgba8.argtypes = [vp]; l.rt_device_rgba8.restype = vp
+        l.rt_device_accum.argtypes = [vp]; l.rt_device_accum.restype = vp
+        l.rt_last_error.argtypes = [vp]; l.rt_last_error.restype = C.c_char_p
+        l.rt_abi_version.argtypes = []; l.rt_abi_version.restype = C.c_int32
+        _lib = l
+    return _lib
+
+
+def host() -> C.CDLL:
+    """Loads librt_host.so, the C++ mirror of the reference's Scene / Camera / Renderer API."""
+    global _host
+    if _host is None:
+        lib()
+        if not os.path.exists(HOST_LIB_PATH):
+            raise FileNotFoundError(f"{HOST_LIB_PATH} is missing: build it with `make -C ray-tracing_amd/csrc`")
+        h = C.CDLL(HOST_LIB_PATH)
+        vp = C.c_void_p
+        h.rth_scene_build.argtypes = [C.c_char_p]; h.rth_scene_build.restype = vp
+        h.rth_scene_free.argtypes = [vp]; h.rth_scene_free.restype = None
+        h.rth_scene_desc.argtypes = [vp]; h.rth_scene_desc.restype = C.POINTER(rt_scene_desc)
+        h.rth_scene_camera.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(rt_camera_desc)]; h.rth_scene_camera.restype = None
+        h.rth_scene_renderer_accumulation.argtypes = [vp]; h.rth_scene_renderer_accumulation.restype = C.c_int32
+        h.rth_camera.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.POINTER(rt_camera_desc)]
+        h.rth_camera.restype = None
+        h.rth_object_update.argtypes = [C.POINTER(rt_object)]; h.rth_object_update.restype = None
+        h.rth_render_frames.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32),
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_char_p, C.c_size_t]
+        h.rth_render_frames.restype = C.c_int32
+        _host = h
+    return _host
+
+
+# --------------------------------------------------------------------------------------------
+# scenes (built by the C++ host mirror) and textures
+# --------------------------------------------------------------------------------------------
+TEXTURE_FILES = ["chess.png", "wood.png", "stone3.jpg", "earth_clouds.jpg"]  # slots 0..3 of scenes 1, 3, 4
+TEXTURE_DIR = os.path.join(REPO_ROOT, "tests", "golden", "textures")
+
+_tex_cache: dict = {}
+
+
+def load_textures(directory: str = TEXTURE_DIR) -> list:
+    """Decodes the four images the reference's binaries load into tightly packed RGB8 arrays (h, w, 3).
+
+    The reference decodes with the `image` crate (src/utils/image.rs:13-29); here PIL does it on the
+    caller's side of the C ABI.  PNG decoding is lossless; JPEG decoders may differ by an LSB or two,
+    which is why decoding stays outside the boundary.
+    """
+    if directory not in _tex_cache:
+        from PIL import Image
+        out = []
+        for name in TEXTURE_FILES:
+            img = Image.open(os.path.join(directory, name)).convert("RGB")
+            out.append(np.ascontiguousarray(np.asarray(img, dtype=np.uint8)))
+        _tex_cache[directory] = out
+    return _tex_cache[directory]
+
+
+class Scene:
+    """A scene built by the host mirror: owns the flat arrays `desc` points into."""
+
+    def __init__(self, name: str):
+        self._h = host()
+        self._p = self._h.rth_scene_build(name.encode())
+        if not self._p:
+            raise ValueError(f"unknown scene {name!r}")
+        self.name = name
+        # private copy of the descriptor so that flags can be overridden per test
+        self.desc = rt_scene_desc()
+        C.memmove(C.byref(self.desc), self._h.rth_scene_desc(self._p), C.sizeof(rt_scene_desc))
+        self.renderer_accumulation = bool(self._h.rth_scene_renderer_accumulation(self._p))
+
+    def camera(self, width: int, height: int) -> rt_camera_desc:
+        cam = rt_camera_desc()
+        self._h.rth_scene_camera(self._p, width, height, C.byref(cam))
+        return cam
+
+    def textures(self) -> list:
+        return load_textures()[: self.desc.n_textures]
+
+    def handle(self):
+        return self._p
+
+    def __del__(self):
+        try:
+            if self._p:
+                self._h.rth_scene_free(self._p)
+                self._p = None
+        except Exception:
+            pass
+
+
+def make_camera(position: Sequence[float], look_at: Sequence[float], width: int, height: int) -> rt_camera_desc:
+    """Camera::new_with_pos(position, look_at) followed by a Resize event (src/camera.rs:70-95)."""
+    cam = rt_camera_desc()
+    p = (C.c_float * 3)(*position)
+    d = (C.c_float * 3)(*look_at)
+    host().rth_camera(p, d, width, height, C.byref(cam))
+    return cam
+
+
+# --------------------------------------------------------------------------------------------
+# context wrapper
+# --------------------------------------------------------------------------------------------
+class Context:
+    """One rt_ctx: one GPU, one thread at a time."""
+
+    def __init__(self, device_id: int = 0):
+        self._l = lib()
+        self._ctx = C.c_void_p()
+        st = self._l.rt_create(device_id, C.byref(self._ctx))
+        if st != 0:
+            self._ctx = C.c_void_p()
+            raise BackendError(f"rt_create(device {device_id}) failed with status {st}: no usable MI355X device?")
+        self.width = 0
+        self.height = 0
+        self._keep = []
+
+    def _check(self, st: int, what: str):
+        if st != 0:
+            raise BackendError(f"{what} failed ({st}): {self._l.rt_last_error(self._ctx).decode()}")
+
+    def set_scene(self, desc: rt_scene_desc):
+        self._check(self._l.rt_set_scene(self._ctx, C.byref(desc)), "rt_set_scene")
+
+    def set_texture(self, index: int, rgb: np.ndarray):
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        assert rgb.ndim == 3 and rgb.shape[2] == 3
+        self._check(self._l.rt_set_texture(self._ctx, index, rgb.shape[1], rgb.shape[0], rgb.ctypes.data), "rt_set_texture")
+
+    def set_camera(self, cam: rt_camera_desc):
+        self._check(self._l.rt_set_camera(self._ctx, C.byref(cam)), "rt_set_camera")
+        self.width, self.height = cam.width, cam.height
+
+    def load(self, scene: Scene, width: int, height: int):
+        """Uploads a host-mirror scene, its textures and its camera."""
+        for i, t in enumerate(scene.textures()):
+            self.set_texture(i, t)
+        self.set_scene(scene.desc)
+        self.set_camera(scene.camera(width, height))
+
+    def render(self, frame_index: int = 1, accumulate: bool = False, reset_accum: bool = False, seed: int = 0x5EED) -> np.ndarray:
+        """rt_render: one frame into a host array (h, w, 4) uint8."""
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self._check(self._l.rt_render(self._ctx, frame_index, int(accumulate), int(reset_accum), seed, out.ctypes.data, out.nbytes), "rt_render")
+        return out
+
+    def render_device(self, frame_index: int = 1, accumulate: bool = False, seed: int = 0x5EED, rows: Optional[tuple] = None,
+                      collect_events: bool = False, d_rgba8: int = 0, d_accum: int = 0, stream: int = 0):
+        """rt_render_device: asynchronous launch into device buffers (0 = the context's own)."""
+        p = rt_render_params()
+        p.frame_index = frame_index
+        p.accumulate = int(accumulate)
+        p.collect_events = int(collect_events)
+        p.seed = seed
+        if rows is not None:
+            p.row_begin, p.row_end = rows
+        self._check(self._l.rt_render_device(self._ctx, C.byref(p), C.c_void_p(d_rgba8 or None), C.c_void_p(d_accum or None),
+                                             C.c_void_p(stream or None)), "rt_render_device")
+
+    def reset_accum(self):
+        self._check(self._l.rt_reset_accum(self._ctx), "rt_reset_accum")
+
+    def read_accum(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._l.rt_read_accum(self._ctx, out.ctypes.data, self.width * self.height), "rt_read_accum")
+        return out
+
+    def stats(self) -> dict:
+        s = rt_stats()
+        self._check(self._l.rt_get_stats(self._ctx, C.byref(s)), "rt_get_stats")
+        d = {name: int(s.counters[i]) for i, name in enumerate(COUNTER_NAMES)}
+        d["rays_total"] = int(s.rays_total)
+        d["last_kernel_ms"] = float(s.last_kernel_ms)
+        d["last_copy_ms"] = float(s.last_copy_ms)
+        d["frames_rendered"] = int(s.frames_rendered)
+        return d
+
+    def device_rgba8(self) -> int:
+        return int(self._l.rt_device_rgba8(self._ctx) or 0)
+
+    def device_accum(self) -> int:
+        return int(self._l.rt_device_accum(self._ctx) or 0)
+
+    def close(self):
+        if self._ctx:
+            self._l.rt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_rows(height: int, rank: int, world_size: int, band: int = 8) -> tuple:
+    """Row band [begin, end) of `rank` when a frame is split over `world_size` GPUs.
+
+    Bands are contiguous and aligned to the kernels' 8-row tiles; the last ranks may get one band less.
+    """
+    n_bands = (height + band - 1) // band
+    base, extra = divmod(n_bands, world_size)
+    first = rank * base + min(rank, extra)
+    count = base + (1 if rank < extra else 0)
+    return min(first * band, height), min((first + count) * band, height)

@@ -1,0 +1,94 @@
+// rt_dev_scene.h — flat device-side records of Scene / Camera (reference: src/scene.rs:13-25,
+// src/objects.rs:21-30,151-160, src/light.rs:29-33, src/camera.rs:6-20), shared by the host upload code
+// and the kernels.
+//
+// Layout rule: everything a whole wavefront reads at the same index (objects in the closest-hit loop,
+// lights, the sdf list, camera matrices) is an array of small records read through scalar loads into
+// SGPRs; only per-lane data (texels, BVH nodes, frame buffers) goes through vector memory.
+#pragma once
+#include <stdint.h>
+
+// (M * vec4(v, w)).xyz needs the x,y,z rows only: four columns of three floats, plus the column-3-times-zero
+// term glam still adds for directions (w = 0), pre-multiplied on the host so the kernel adds it verbatim.
+struct DevXform {
+    float c0[3], c1[3], c2[3], c3[3];
+    float z[3];  // c3 * 0.0f
+};
+
+struct DevObject {
+    int32_t kind;      // rt_object_kind
+    int32_t material;  // material index (0 for Union / Substraction)
+    int32_t first, second;
+    DevXform inv;  // inv_transform
+    DevXform fwd;  // transform
+    // kind-specific parameters:
+    //   Sphere   p[0] radius
+    //   Cuboid   p[0..2] dimension
+    //   Plane    p[0..2] normal, p[3..5] point, p[6..7] max_dist, p[8] has_max_dist (0/1)
+    //   Cylinder p[0] radius, p[1] height
+    //   Triangle p[0..2] v1, p[3..5] v2, p[6..8] v3
+    float p[12];
+};
+
+struct DevMaterial {
+    float ambience, diffuse, specular, shininess;
+    float albedo[3];
+    int32_t texture;  // -1: none
+    int32_t kind;     // rt_material_kind
+    float roughness, transparency, refraction_index, reflectivity, emission_power;
+    float pad[2];
+};
+
+struct DevLight {
+    int32_t kind;  // rt_light_kind
+    float albedo[3];
+    float vec[3];
+    float intensity;
+};
+
+// One texel per dword (R | G<<8 | B<<16), repacked from the caller's RGB8 once at upload.
+struct DevTexture {
+    const uint32_t *texels;
+    uint32_t width, height;
+};
+
+// Bounding-volume hierarchy over the sphere objects of a large scene (not part of the reference,
+// which scans all objects linearly; results are identical, see the traversal's tie rule).
+struct DevBvhNode {
+    float lo[3];
+    int32_t left;   // inner: index of the left child; leaf: first index into the primitive list
+    float hi[3];
+    int32_t count;  // 0: inner node (right child = left + 1); > 0: leaf with `count` primitives
+};
+
+struct DevScene {
+    const DevObject *objects;
+    const DevMaterial *materials;
+    const DevLight *lights;
+    const uint32_t *sdfs;
+    const DevTexture *textures;
+    const DevBvhNode *bvh_nodes;   // null: linear scan
+    const uint32_t *bvh_prims;     // object indices, leaf order
+    uint32_t n_objects, n_materials, n_lights, n_sdfs;
+    float ambient[3];
+    uint32_t max_ray_bounces;
+    uint32_t shadow_casting, ray_marching, diffuse, enable_accumulation;
+};
+
+struct DevCamera {
+    float ip_c0[4], ip_c1[4], ip_c2[4], ip_c3[4];  // inverse_perspective columns
+    DevXform iv;                                   // inverse_view
+    float position[3];
+    uint32_t width, height;
+    float inv_w, inv_h;  // 1 / width as f32, 1 / height as f32 (src/camera.rs:132-133)
+};
+
+struct DevFrame {
+    uint32_t frame_index;
+    uint32_t row_begin, row_end;
+    int32_t accumulate;
+    uint64_t seed;
+    uint32_t *rgba;      // width*height packed R | G<<8 | B<<16 | A<<24
+    float *accum;        // width*height float4
+    uint32_t *counters;  // [gridDim.x][n_counters]
+};

@@ -1,0 +1,874 @@
+// rt_kernels.h — hand-written gfx950 kernels for the per-pixel hot path of mariusdanciu/ray-tracing.
+//
+//   rt_trace_kernel   Scene::pixel with ray_marching == false: camera ray generation
+//                     (src/camera.rs:128-157), RayTracing::{albedo,color,color_diffuse,light,trace_ray}
+//                     (src/ray_tracing/ray_tracing.rs:17-241), the six Intersection impls, Blinn-Phong,
+//                     reflection / refraction rays, Fresnel, nearest-texel sampling, then
+//                     render_chunk's accumulate / clamp / to_rgba (src/renderer.rs:59-75).
+//   rt_march_kernel   Scene::pixel with ray_marching == true: RayMarching::{albedo,march_ray,sdfs,normal,
+//                     occlusion,light} (src/ray_marching/ray_marching.rs:24-253) and the sdf() impls.
+//
+// Execution model: one lane per pixel, one wavefront per 8x8 pixel tile.  The closest-hit loop runs over
+// the object array with a wave-uniform index, so object records arrive through scalar loads and the
+// per-kind switch does not diverge.  The reference's recursion is an explicit state machine: a lane is
+// either descending (tracing one ray and shading its hit) or unwinding pending combines.  Reflective
+// frames (p_light, roughness) live in LDS, one column per lane; refractive frames (two children) live
+// in a small per-lane array.  Intersection candidates only produce t; normal / UV / point are computed
+// once for the closest one, with the same arithmetic the reference applies to every candidate.
+#pragma once
+#include "../../include/rt_mi355x.h"
+#include "rt_dev_math.h"
+#include "rt_dev_scene.h"
+
+#pragma clang fp contract(off)
+
+#define RT_EPSILON 0.0001f                        // src/ray.rs:9
+#define RT_INV_PI (1.0f / 3.14159274101257324f)   // src/utils/sphere.rs:13
+#define RT_F32_MAX 3.40282347e+38f
+
+// ------------------------------------------------------------------------------------------------
+// per-lane counters, summed per workgroup at kernel end
+// ------------------------------------------------------------------------------------------------
+template <bool EVENTS>
+struct Cnt {
+    uint32_t rays;
+    uint32_t ev[EVENTS ? RT_CNT_COUNT : 1];
+    RT_DEV void clear() {
+        rays = 0;
+#pragma unroll
+        for (int i = 0; i < (EVENTS ? RT_CNT_COUNT : 1); i++) ev[i] = 0;
+    }
+    RT_DEV void add(int slot) { if (EVENTS) ev[slot] += 1u; }
+    RT_DEV void ray(int slot) { rays += 1u; if (EVENTS) ev[slot] += 1u; }
+};
+
+RT_DEV f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+// (M * vec4(v, 0)).xyz and (M * vec4(v, 1)).xyz in glam's order: ((c0*x + c1*y) + c2*z) + c3*w
+RT_DEV f3 xf_dir(const DevXform &m, f3 v) {
+    return mk3(((m.c0[0] * v.x + m.c1[0] * v.y) + m.c2[0] * v.z) + m.z[0], ((m.c0[1] * v.x + m.c1[1] * v.y) + m.c2[1] * v.z) + m.z[1],
+               ((m.c0[2] * v.x + m.c1[2] * v.y) + m.c2[2] * v.z) + m.z[2]);
+}
+RT_DEV f3 xf_pt(const DevXform &m, f3 v) {
+    return mk3(((m.c0[0] * v.x + m.c1[0] * v.y) + m.c2[0] * v.z) + m.c3[0], ((m.c0[1] * v.x + m.c1[1] * v.y) + m.c2[1] * v.z) + m.c3[1],
+               ((m.c0[2] * v.x + m.c1[2] * v.y) + m.c2[2] * v.z) + m.c3[2]);
+}
+
+struct Mtl {
+    float ambience, diffuse, specular, shininess;
+    f3 albedo;
+    int texture, kind;
+    float roughness, transparency, refraction_index, reflectivity, emission_power;
+};
+RT_DEV Mtl load_mtl(const DevMaterial &m) {
+    Mtl r;
+    r.ambience = m.ambience; r.diffuse = m.diffuse; r.specular = m.specular; r.shininess = m.shininess;
+    r.albedo = ld3(m.albedo); r.texture = m.texture; r.kind = m.kind; r.roughness = m.roughness;
+    r.transparency = m.transparency; r.refraction_index = m.refraction_index; r.reflectivity = m.reflectivity;
+    r.emission_power = m.emission_power;
+    return r;
+}
+
+struct HitRec { f3 point, normal; float u, v; };
+
+// ------------------------------------------------------------------------------------------------
+// Texture::from_uv (src/objects.rs:121-147)
+// ------------------------------------------------------------------------------------------------
+RT_DEV float rt_textel(float p) {
+    if (p < 0.0f) return 1.0f - rt_abs(__builtin_ceilf(p) - p);
+    else if (p > 1.0f) return p - __builtin_floorf(p);
+    return p;
+}
+RT_DEV f3 tex_from_uv(const DevTexture &t, float u, float v) {
+    float uu = rt_textel(u), vv = rt_textel(v);
+    uint32_t x = rt_as_u32((float)(t.width - 1u) * uu);
+    uint32_t y = rt_as_u32((float)(t.height - 1u) * vv);
+    uint32_t px = t.texels[y * t.width + x];
+    const float RGB_RATIO = 1.0f / 255.0f;
+    return mk3((float)(px & 255u) * RGB_RATIO, (float)((px >> 8) & 255u) * RGB_RATIO, (float)((px >> 16) & 255u) * RGB_RATIO);
+}
+
+// ------------------------------------------------------------------------------------------------
+// candidate phase of the Intersection impls: Some/None and `distance` only
+// ------------------------------------------------------------------------------------------------
+RT_DEV bool cand_sphere(const DevObject &o, f3 ro_w, f3 rd_w, float &t) {  // src/utils/sphere.rs:99-125
+    f3 rd = xf_dir(o.inv, rd_w), ro = xf_pt(o.inv, ro_w);
+    float a = dot(rd, rd);
+    float b = 2.0f * dot(ro, rd);
+    float c = dot(ro, ro) - 1.0f;
+    float disc = b * b - 4.0f * a * c;
+    if (disc < 0.0f) return false;
+    t = (-b - rt_sqrt(disc)) / (2.0f * a);
+    return true;
+}
+RT_DEV bool cand_plane(const DevObject &o, f3 ro, f3 rd, float &t) {  // src/utils/plane.rs:42-59
+    f3 n = ld3(o.p), pt = ld3(o.p + 3);
+    float denom = dot(rd, n);
+    if (rt_abs(denom) < 1e-6f) return false;
+    t = dot(pt - ro, n) / denom;
+    if (t < 0.0f) return false;
+    f3 hp = ro + rd * t;
+    if (o.p[8] != 0.0f) {
+        if (rt_abs(hp.z) > o.p[7] || rt_abs(hp.x) > o.p[6]) return false;
+    }
+    return true;
+}
+RT_DEV bool cand_cuboid(const DevObject &o, f3 ro_w, f3 rd_w, float &t) {  // src/utils/cuboid.rs:85-105
+    f3 rd = xf_dir(o.inv, rd_w), ro = xf_pt(o.inv, ro_w);
+    f3 inv = 1.0f / rd;
+    f3 t_min = (ld3(o.p + 3) - ro) * inv;
+    f3 t_max = (ld3(o.p + 6) - ro) * inv;
+    f3 t_enter = vmin(t_min, t_max), t_exit = vmax(t_min, t_max);
+    float t_near = rt_max(rt_max(t_enter.x, t_enter.y), t_enter.z);
+    float t_far = rt_min(rt_min(t_exit.x, t_exit.y), t_exit.z);
+    if (t_near > t_far || t_far < 0.0f) return false;
+    t = t_near;
+    return true;
+}
+// sub: 0 = lateral surface, 1 = cap
+RT_DEV bool cand_cylinder(const DevObject &o, f3 ro_w, f3 rd_w, float &t, int &sub) {  // src/utils/cylinder.rs:91-158
+    f3 rd3 = xf_dir(o.inv, rd_w), ro3 = xf_pt(o.inv, ro_w);
+    float a = (rd3.x * rd3.x) + (rd3.y * rd3.y);
+    float b = 2.0f * ((ro3.x * rd3.x) + (ro3.y * rd3.y));
+    float c = ((ro3.x * ro3.x) + (ro3.y * ro3.y)) - 1.0f;
+    float disc = b * b - 4.0f * a * c;
+    if (disc > 0.0f) {
+        float t1 = (-b - rt_sqrt(disc)) / (2.0f * a);
+        f3 h = ro3 + rd3 * t1;
+        if (rt_abs(h.z) < 0.5f) { t = t1; sub = 0; return true; }
+    }
+    float inv_rd3z = -1.0f / rd3.z;
+    float t1 = (ro3.z - 0.5f) * inv_rd3z;
+    float t2 = (ro3.z + 0.5f) * inv_rd3z;
+    f3 h1 = ro3 + rd3 * t1, h2 = ro3 + rd3 * t2;
+    bool v1 = ((h1.x * h1.x) + (h1.y * h1.y)) < 1.0f;
+    bool v2 = ((h2.x * h2.x) + (h2.y * h2.y)) < 1.0f;
+    sub = 1;
+    if (v1 && v2) { t = (t1 < t2) ? t1 : t2; return true; }
+    if (v1) { t = t1; return true; }
+    if (v2) { t = t2; return true; }
+    return false;
+}
+// sub: 0 = lateral surface, 1 = cap
+RT_DEV bool cand_cone(const DevObject &o, f3 ro_w, f3 rd_w, float &t, int &sub) {  // src/utils/cone.rs:74-151
+    f3 rd3 = xf_dir(o.inv, rd_w), ro3 = xf_pt(o.inv, ro_w);
+    float a = ((rd3.x * rd3.x) + (rd3.y * rd3.y)) - rd3.z * rd3.z;
+    float b = 2.0f * (((ro3.x * rd3.x) + (ro3.y * rd3.y)) - ro3.z * rd3.z);
+    float c = ((ro3.x * ro3.x) + (ro3.y * ro3.y)) - ro3.z * ro3.z;
+    float disc = b * b - 4.0f * a * c;
+    bool have_cone = false;
+    float t_cone = 0.0f;
+    if (disc > 0.0f) {
+        float t1 = (-b - rt_sqrt(disc)) / (2.0f * a);
+        f3 h = ro3 + rd3 * t1;
+        if (h.z > 0.0f && h.z < 1.0f) { have_cone = true; t_cone = t1; }
+    }
+    float t1 = (ro3.z - 1.0f) / -rd3.z;
+    f3 h1 = ro3 + rd3 * t1;
+    bool valid = ((h1.x * h1.x) + (h1.y * h1.y)) < 1.0f;
+    if (valid) {
+        if (have_cone && t_cone < t1) { t = t_cone; sub = 0; return true; }
+        t = t1; sub = 1; return true;
+    }
+    if (have_cone) { t = t_cone; sub = 0; return true; }
+    return false;
+}
+RT_DEV bool cand_triangle(const DevObject &o, f3 ro, f3 rd, float &t) {  // src/utils/triangle.rs:36-68
+    f3 v1 = ld3(o.p), v2 = ld3(o.p + 3), v3 = ld3(o.p + 6);
+    f3 edge_ab = v2 - v1, edge_ac = v3 - v1;
+    f3 normal = cross(edge_ab, edge_ac);
+    float denom = dot(rd, normal);
+    if (rt_abs(denom) < 1e-6f) return false;
+    t = dot(v1 - ro, normal) / denom;
+    f3 hp = ro + rd * t;
+    f3 edge_bc = v3 - v2, edge_ca = v1 - v3;
+    f3 a_test = cross(edge_ab, hp - v1), b_test = cross(edge_bc, hp - v2), c_test = cross(edge_ca, hp - v3);
+    bool a_n = dot(a_test, normal) > 0.0f, b_n = dot(b_test, normal) > 0.0f, c_n = dot(c_test, normal) > 0.0f;
+    return a_n && b_n && c_n;
+}
+
+RT_DEV int test_slot(int kind) {
+    switch (kind) {
+        case RT_SPHERE: return RT_CNT_TEST_SPHERE; case RT_TRIANGLE: return RT_CNT_TEST_TRIANGLE;
+        case RT_CUBOID: return RT_CNT_TEST_CUBOID; case RT_PLANE: return RT_CNT_TEST_PLANE;
+        case RT_CYLINDER: return RT_CNT_TEST_CYLINDER; default: return RT_CNT_TEST_CONE;
+    }
+}
+
+// RayTracing::trace_ray (src/ray_tracing/ray_tracing.rs:59-78): linear scan, accept 0 < t < closest (strict),
+// so the lowest index wins ties.  Returns the object index or -1.
+template <bool EVENTS>
+RT_DEV int trace_closest(const DevScene &S, f3 ro, f3 rd, float &t_out, int &sub_out, Cnt<EVENTS> &cnt, int ray_slot) {
+    const uint32_t n = S.n_objects;
+    if (n == 0u) return -1;
+    cnt.ray(ray_slot);
+    float closest = RT_F32_MAX;
+    int best = -1, best_sub = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const DevObject &o = S.objects[i];
+        float t = 0.0f;
+        int sub = 0;
+        bool ok = false;
+        switch (o.kind) {
+            case RT_SPHERE: cnt.add(RT_CNT_TEST_SPHERE); ok = cand_sphere(o, ro, rd, t); break;
+            case RT_TRIANGLE: cnt.add(RT_CNT_TEST_TRIANGLE); ok = cand_triangle(o, ro, rd, t); break;
+            case RT_CUBOID: cnt.add(RT_CNT_TEST_CUBOID); ok = cand_cuboid(o, ro, rd, t); break;
+            case RT_PLANE: cnt.add(RT_CNT_TEST_PLANE); ok = cand_plane(o, ro, rd, t); break;
+            case RT_CYLINDER: cnt.add(RT_CNT_TEST_CYLINDER); ok = cand_cylinder(o, ro, rd, t, sub); break;
+            case RT_CONE: cnt.add(RT_CNT_TEST_CONE); ok = cand_cone(o, ro, rd, t, sub); break;
+            default: break;  // Union / Substraction: Ray::hit's `_ => None` (src/ray.rs:175)
+        }
+        if (ok && t > 0.0f && t < closest) { closest = t; best = (int)i; best_sub = sub; }
+    }
+    t_out = closest;
+    sub_out = best_sub;
+    return best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalise phase: RayHit of the closest candidate, same arithmetic as the reference's intersect()
+// ------------------------------------------------------------------------------------------------
+RT_DEV void fin_sphere(const DevObject &o, f3 ro_w, f3 rd_w, float t1, bool need_uv, HitRec &h) {  // sphere.rs:127-146
+    f3 rd = xf_dir(o.inv, rd_w), ro = xf_pt(o.inv, ro_w);
+    f3 l = ro + rd * t1;
+    h.normal = normalize(xf_dir(o.fwd, l));
+    h.point = ro_w + rd_w * t1;
+    if (need_uv) {
+        float u = rt_atanf((l.x * l.x + l.y * l.y) / l.z);
+        float v = rt_atanf(l.y / l.x);
+        h.u = v * RT_INV_PI;
+        h.v = u * RT_INV_PI;
+    }
+}
+RT_DEV void fin_plane(const DevObject &o, f3 ro, f3 rd, float t, HitRec &h) {  // plane.rs:53-73
+    f3 n = ld3(o.p);
+    f3 hp = ro + rd * t;
+    float sign = -1.0f;
+    if (dot(rd, n) < 0.0f) sign = 1.0f;
+    h.point = hp;
+    h.normal = sign * n;
+    h.u = hp.x * 0.1f;
+    h.v = hp.z * 0.1f;
+}
+RT_DEV void fin_cuboid(const DevObject &o, f3 ro_w, f3 rd_w, float t_near, HitRec &h) {  // cuboid.rs:92-126
+    f3 rd = xf_dir(o.inv, rd_w), ro = xf_pt(o.inv, ro_w);
+    f3 inv = 1.0f / rd;
+    f3 t_min = (ld3(o.p + 3) - ro) * inv;
+    f3 t_max = (ld3(o.p + 6) - ro) * inv;
+    f3 t_enter = vmin(t_min, t_max);
+    f3 sg = mk3(rt_signum(rd.x), rt_signum(rd.y), rt_signum(rd.z));
+    f3 st = mk3(t_enter.x < t_near ? 0.0f : 1.0f, t_enter.y < t_near ? 0.0f : 1.0f, t_enter.z < t_near ? 0.0f : 1.0f);
+    f3 a = (-sg) * st;
+    h.normal = xf_dir(o.fwd, a);
+    h.point = ro_w + rd_w * t_near;
+    f3 opos = xf_pt(o.inv, h.point);
+    float ax = rt_abs(a.x), ay = rt_abs(a.y), az = rt_abs(a.z);
+    h.u = (ax * opos.y + ay * opos.z) + az * opos.x;
+    h.v = (ax * opos.z + ay * opos.x) + az * opos.y;
+}
+RT_DEV void fin_cylinder(const DevObject &o, f3 ro_w, f3 rd_w, float t, int sub, bool need_uv, HitRec &h) {  // cylinder.rs:108-173
+    f3 rd3 = xf_dir(o.inv, rd_w), ro3 = xf_pt(o.inv, ro_w);
+    f3 ht = ro3 + rd3 * t;
+    h.point = ro_w + rd_w * t;
+    if (sub == 0) {
+        h.normal = normalize(xf_dir(o.fwd, mk3(ht.x, ht.y, 0.0f)));
+        if (need_uv) h.u = rt_atanf(ht.y / ht.x);
+        h.v = ht.z * 2.0f;
+    } else {
+        h.normal = normalize(xf_dir(o.fwd, mk3(0.0f, 0.0f, ht.z)));
+        h.u = ht.x;
+        h.v = ht.y;
+    }
+}
+RT_DEV void fin_cone(const DevObject &o, f3 ro_w, f3 rd_w, float t, int sub, bool need_uv, HitRec &h) {  // cone.rs:93-148
+    f3 rd3 = xf_dir(o.inv, rd_w), ro3 = xf_pt(o.inv, ro_w);
+    f3 ht = ro3 + rd3 * t;
+    h.point = ro_w + rd_w * t;
+    if (sub == 0) {
+        f3 n = mk3(ht.x, ht.y, -rt_sqrt(ht.x * ht.x + ht.y * ht.y));
+        h.normal = normalize(xf_dir(o.fwd, n));
+        if (need_uv) h.u = rt_atanf(ht.y / ht.x);
+        h.v = ht.z * 2.0f + 1.0f;
+    } else {
+        h.normal = xf_dir(o.fwd, mk3(0.0f, 0.0f, 1.0f));
+        h.u = ht.x;
+        h.v = ht.y;
+    }
+}
+RT_DEV void fin_triangle(const DevObject &o, f3 ro, f3 rd, float t, HitRec &h) {  // triangle.rs:49-88
+    f3 v1 = ld3(o.p), v2 = ld3(o.p + 3), v3 = ld3(o.p + 6);
+    f3 edge_ab = v2 - v1, edge_ac = v3 - v1;
+    f3 n = cross(edge_ab, edge_ac);
+    f3 hp = ro + rd * t;
+    f3 edge_ca = v1 - v3;
+    float sign = -rt_signum(dot(rd, n));
+    h.u = dot(cross(edge_ab, hp - v1), n);
+    h.v = dot(cross(edge_ca, hp - v3), n);
+    h.point = hp;
+    h.normal = normalize(sign * n);
+}
+
+// Completes the closest hit of every lane.  Lanes of a wave usually share a handful of winners, so the
+// loop visits each distinct winner once with a wave-uniform object (scalar loads, no divergent switch).
+template <bool EVENTS>
+RT_DEV void finalize_hit(const DevScene &S, f3 ro, f3 rd, float t, int obj, int sub, HitRec &h, Mtl &m, Cnt<EVENTS> &cnt) {
+    h.u = 0.0f; h.v = 0.0f;
+    int pending = obj;
+    while (true) {
+        int cur = __builtin_amdgcn_readfirstlane(pending);
+        if (pending == cur) {
+            const DevObject &o = S.objects[cur];
+            const DevMaterial &dm = S.materials[o.material];
+            m = load_mtl(dm);
+            const bool need_uv = dm.texture >= 0 && dm.kind == RT_REFLECTIVE;
+            switch (o.kind) {
+                case RT_SPHERE: cnt.add(RT_CNT_HIT_SPHERE); fin_sphere(o, ro, rd, t, need_uv, h); break;
+                case RT_TRIANGLE: cnt.add(RT_CNT_HIT_TRIANGLE); fin_triangle(o, ro, rd, t, h); break;
+                case RT_CUBOID: cnt.add(RT_CNT_HIT_CUBOID); fin_cuboid(o, ro, rd, t, h); break;
+                case RT_PLANE: cnt.add(RT_CNT_HIT_PLANE); fin_plane(o, ro, rd, t, h); break;
+                case RT_CYLINDER: cnt.add(RT_CNT_HIT_CYLINDER); fin_cylinder(o, ro, rd, t, sub, need_uv, h); break;
+                default: cnt.add(RT_CNT_HIT_CONE); fin_cone(o, ro, rd, t, sub, need_uv, h); break;
+            }
+            break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// shading
+// ------------------------------------------------------------------------------------------------
+// Ray::blinn_phong (src/ray.rs:68-85) with light.direction(hit.point) evaluated once (it is pure).
+RT_DEV f3 blinn_phong(f3 ray_dir, f3 normal, f3 ldir, f3 color, const Mtl &m) {
+    float coeff = dot(normal, -ldir);
+    f3 ambience = m.ambience * color;
+    f3 diffuse = m.diffuse * rt_max(coeff, 0.0f) * color;
+    f3 half_angle = normalize(-ray_dir - ldir);
+    float shininess = rt_powf(rt_max(dot(normal, half_angle), 0.0f), m.shininess);
+    f3 specular = m.specular * shininess * color;
+    return ambience + diffuse + specular;
+}
+
+// LightSource::{direction, distance} (src/light.rs:42-92): one subtraction / length feeds both.
+RT_DEV void light_dir_dist(const DevLight &l, f3 point, f3 &dir, float &dist) {
+    if (l.kind == RT_DIRECTIONAL) { dir = ld3(l.vec); dist = 1.0f; }
+    else { f3 v = point - ld3(l.vec); float len = length(v); dir = v * (1.0f / len); dist = len; }
+}
+
+// RayTracing::light (src/ray_tracing/ray_tracing.rs:28-57)
+template <bool EVENTS>
+RT_DEV f3 shade_lights(const DevScene &S, f3 ray_dir, const HitRec &h, f3 albedo, const Mtl &m, int obj_index, Cnt<EVENTS> &cnt) {
+    cnt.add(RT_CNT_LIGHT_CALL);
+    f3 l_acc = splat3(0.0f);
+    const uint32_t nl = S.n_lights;
+    for (uint32_t i = 0; i < nl; i++) {
+        const DevLight &l = S.lights[i];
+        cnt.add(RT_CNT_LIGHT_SHADE);
+        f3 ldir; float ldist;
+        light_dir_dist(l, h.point, ldir, ldist);
+        f3 k = blinn_phong(ray_dir, h.normal, ldir, albedo, m);
+        l_acc = l_acc + (k / (ldist * ldist)) * ld3(l.albedo) * l.intensity;
+    }
+    if (S.shadow_casting) {
+        f3 so = h.point + RT_EPSILON * h.normal;
+        for (uint32_t i = 0; i < nl; i++) {
+            const DevLight &l = S.lights[i];
+            f3 ldir; float ldist;
+            light_dir_dist(l, h.point, ldir, ldist);
+            float st; int ssub;
+            int idx = trace_closest<EVENTS>(S, so, -ldir, st, ssub, cnt, RT_CNT_RAYS_SHADOW);
+            if (idx >= 0 && idx != obj_index) l_acc = l_acc * 0.5f;
+        }
+    }
+    return vpowf(l_acc, 0.4166f);
+}
+
+RT_DEV f3 rt_reflect(f3 vec, f3 normal) { return vec - (2.0f * dot(vec, normal)) * normal; }  // geometry.rs:7-9
+
+// Material::fresnel (src/objects.rs:178-205); returns kr
+RT_DEV float rt_fresnel(f3 incident, f3 normal, float refraction_index, float reflectivity) {
+    float n2 = refraction_index, n1 = 1.0f;
+    float r0 = (n1 - n2) / (n1 + n2);
+    r0 = r0 * r0;
+    float cos_x = dot(normal, -incident);
+    if (n1 > n2) {
+        float n = n1 / n2;
+        float sin_t2 = n * n * (1.0f - cos_x * cos_x);
+        if (sin_t2 > 1.0f) return 1.0f;
+        cos_x = rt_sqrt(1.0f - sin_t2);
+    }
+    float x = 1.0f - cos_x;
+    float ret = r0 + (1.0f - r0) * x * x * x * x * x;
+    return reflectivity + (1.0f - reflectivity) * ret;
+}
+
+// Ray::refraction_ray (src/ray.rs:138-165)
+RT_DEV bool rt_refraction_ray(f3 ray_dir, const HitRec &h, float refraction_index, f3 &o, f3 &d) {
+    f3 normal = h.normal;
+    float eta_t = refraction_index, eta_i = 1.0f;
+    float c1 = dot(ray_dir, h.normal);
+    if (c1 < 0.0f) { c1 = -c1; }
+    else { normal = -normal; eta_i = eta_t; eta_t = 1.0f; }
+    float eta = eta_i / eta_t;
+    float k = 1.0f - eta * eta * (1.0f - c1 * c1);
+    if (k < 0.0f) return false;
+    float c2 = rt_sqrt(k);
+    d = eta * ray_dir + normal * (eta * c1 - c2);
+    o = h.point - RT_EPSILON * normal;
+    return true;
+}
+
+// Ray::reflection_ray (src/ray.rs:101-136)
+RT_DEV void rt_reflection_ray(f3 ray_dir, const HitRec &h, float roughness, uint32_t key, bool diffuse, bool jitter, f3 &o, f3 &d) {
+    if (!diffuse) {
+        f3 factor = splat3(0.0f);
+        if (jitter) factor = roughness * mk3(rt_rng_uniform(key, 0u, -0.5f, 0.5f), rt_rng_uniform(key, 1u, -0.5f, 0.5f), rt_rng_uniform(key, 2u, -0.5f, 0.5f));
+        d = normalize(rt_reflect(ray_dir, h.normal + factor));
+    } else {
+        f3 rnd = mk3(rt_rng_uniform(key, 0u, -1.0f, 1.0f), rt_rng_uniform(key, 1u, -1.0f, 1.0f), rt_rng_uniform(key, 2u, -1.0f, 1.0f));
+        d = normalize(h.normal + rnd);
+    }
+    o = h.point + h.normal * RT_EPSILON;
+}
+
+// Camera::calculate_ray_directions for one pixel (src/camera.rs:137-148)
+RT_DEV f3 camera_ray(const DevCamera &C, uint32_t x, uint32_t y) {
+    float p_ndc_x = (float)x * C.inv_w, p_ndc_y = (float)y * C.inv_h;
+    float sx = 2.0f * p_ndc_x - 1.0f, sy = 2.0f * p_ndc_y - 1.0f;
+    // inverse_perspective * vec4(sx, sy, 1, 1); the products by 1.0 are exact
+    float tx = ((C.ip_c0[0] * sx + C.ip_c1[0] * sy) + C.ip_c2[0]) + C.ip_c3[0];
+    float ty = ((C.ip_c0[1] * sx + C.ip_c1[1] * sy) + C.ip_c2[1]) + C.ip_c3[1];
+    float tz = ((C.ip_c0[2] * sx + C.ip_c1[2] * sy) + C.ip_c2[2]) + C.ip_c3[2];
+    float tw = ((C.ip_c0[3] * sx + C.ip_c1[3] * sy) + C.ip_c2[3]) + C.ip_c3[3];
+    f3 v = mk3(tx / tw, ty / tw, tz / tw);
+    f3 world = xf_dir(C.iv, v);
+    return normalize(world - ld3(C.position));
+}
+
+// render_chunk's tail (src/renderer.rs:59-75) + to_rgba (:29-36)
+RT_DEV void store_pixel(const DevFrame &F, uint32_t pos, f3 p) {
+    float4 *acc = reinterpret_cast<float4 *>(F.accum) + pos;
+    float4 c;
+    if (F.accumulate) {
+        float4 a = *acc;
+        a.x = a.x + p.x; a.y = a.y + p.y; a.z = a.z + p.z; a.w = a.w + 1.0f;
+        *acc = a;
+        float fi = (float)F.frame_index;
+        c.x = rt_clamp01_sse(a.x / fi); c.y = rt_clamp01_sse(a.y / fi); c.z = rt_clamp01_sse(a.z / fi); c.w = rt_clamp01_sse(a.w / fi);
+    } else {
+        c.x = rt_clamp01_sse(p.x); c.y = rt_clamp01_sse(p.y); c.z = rt_clamp01_sse(p.z); c.w = rt_clamp01_sse(1.0f);
+        *acc = c;
+    }
+    uint32_t r = rt_as_u8(c.x * 255.0f), g = rt_as_u8(c.y * 255.0f), b = rt_as_u8(c.z * 255.0f), a8 = rt_as_u8(c.w + 255.0f);
+    F.rgba[pos] = r | (g << 8) | (b << 16) | (a8 << 24);
+}
+
+// Sums the per-lane counters of a workgroup and writes one row of F.counters.
+template <bool EVENTS>
+RT_DEV void flush_counters(const DevFrame &F, Cnt<EVENTS> &cnt, uint32_t *s_cnt) {
+    constexpr int N = (EVENTS ? RT_CNT_COUNT : 0) + 1;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t vals[N];
+    vals[0] = cnt.rays;
+#pragma unroll
+    for (int i = 1; i < N; i++) vals[i] = cnt.ev[i - 1];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint32_t v = vals[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0u && v != 0u) atomicAdd(&s_cnt[i], v);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (uint32_t)N; i += blockDim.x) F.counters[blockIdx.x * (uint32_t)N + i] = s_cnt[i];
+}
+
+// pixel of this lane: wavefronts enumerate 8x8 tiles row-major over the rendered rows
+RT_DEV bool lane_pixel(const DevCamera &C, const DevFrame &F, uint32_t &x, uint32_t &y) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + wave;
+    const uint32_t tiles_x = (C.width + 7u) >> 3;
+    const uint32_t ty = gw / tiles_x, tx = gw - ty * tiles_x;
+    x = tx * 8u + (lane & 7u);
+    y = F.row_begin + ty * 8u + (lane >> 3);
+    return x < C.width && y < F.row_end;
+}
+
+enum { FK_REFL = 0, FK_REFR1 = 1, FK_REFR2 = 2, FK_PASS = 3 };
+
+// ------------------------------------------------------------------------------------------------
+// ray tracing kernel
+//   REFR   : the scene has refractive materials (two-child frames are compiled in)
+//   RDEPTH : capacity of the per-lane refractive frame array (>= max_ray_bounces when REFR)
+//   dynamic LDS: max_ray_bounces * 4 * blockDim.x floats (reflective frames, one column per lane)
+// ------------------------------------------------------------------------------------------------
+template <bool EVENTS, bool REFR, int RDEPTH>
+__global__ void __launch_bounds__(256) rt_trace_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
+    extern __shared__ float s_frames[];
+    __shared__ uint32_t s_cnt[(EVENTS ? RT_CNT_COUNT : 0) + 1];
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    for (uint32_t i = tid; i < (uint32_t)((EVENTS ? RT_CNT_COUNT : 0) + 1); i += nthr) s_cnt[i] = 0u;
+    __syncthreads();
+
+    Cnt<EVENTS> cnt;
+    cnt.clear();
+    uint32_t px, py;
+    if (lane_pixel(C, F, px, py)) {
+        const uint32_t pos = py * C.width + px;
+        cnt.add(RT_CNT_RAYGEN);
+        cnt.add(RT_CNT_PIXEL_PACK);
+        f3 ro = ld3(C.position);
+        f3 rd = camera_ray(C, px, py);
+        f3 L = splat3(0.0f);      // light_color carried down
+        f3 Cc = splat3(1.0f);     // contribution carried down
+        f3 V = splat3(0.0f);      // value returned by the subtree just finished
+        const f3 ambient = ld3(S.ambient);
+        const uint32_t maxd = S.max_ray_bounces;
+        const bool scene_diffuse = S.diffuse != 0u, jitter = S.enable_accumulation != 0u;
+        bool dmode = scene_diffuse;  // true: inside color_diffuse, false: inside color
+        uint32_t depth = 0u;
+        uint32_t key = rt_rng_path_key(F.seed, pos, F.frame_index);
+        uint64_t kinds = 0ull;    // two bits per frame, frame d at bits [2d, 2d+1]
+        int ray_slot = RT_CNT_RAYS_PRIMARY;
+        float rfr[REFR ? RDEPTH : 1][16];
+        bool done = false;
+        while (!done) {
+            bool have_value = false;
+            // ---- descend: evaluate color / color_diffuse at (ro, rd, depth, L, Cc)
+            if (depth >= maxd) {
+                V = L;
+                have_value = true;
+            } else {
+                float t; int sub;
+                int obj = trace_closest<EVENTS>(S, ro, rd, t, sub, cnt, ray_slot);
+                if (obj < 0) {
+                    V = L + ambient * Cc;
+                    have_value = true;
+                } else {
+                    HitRec h; Mtl m;
+                    finalize_hit<EVENTS>(S, ro, rd, t, obj, sub, h, m, cnt);
+                    f3 albedo = m.albedo;
+                    if (m.kind == RT_REFLECTIVE) {
+                        if (m.texture >= 0) { cnt.add(RT_CNT_TEX_FETCH); albedo = tex_from_uv(S.textures[m.texture], h.u, h.v); }
+                        f3 p;
+                        if (!dmode) p = shade_lights<EVENTS>(S, rd, h, albedo, m, obj, cnt);
+                        else p = L + m.emission_power * albedo;
+                        cnt.add(scene_diffuse ? RT_CNT_DIFFUSE_RAY : RT_CNT_REFLECTION_RAY);
+                        f3 no, nd;
+                        rt_reflection_ray(rd, h, m.roughness, key, scene_diffuse, jitter, no, nd);
+                        if (!dmode) {
+                            float *fr = s_frames + (size_t)(depth * 4u) * nthr + tid;
+                            fr[0] = p.x; fr[nthr] = p.y; fr[2u * nthr] = p.z; fr[3u * nthr] = m.roughness;
+                            kinds = (kinds & ~(3ull << (2u * depth))) | ((uint64_t)FK_REFL << (2u * depth));
+                        } else {
+                            cnt.add(RT_CNT_COMBINE_REFL);
+                            kinds = (kinds & ~(3ull << (2u * depth))) | ((uint64_t)FK_PASS << (2u * depth));
+                        }
+                        ro = no; rd = nd; L = p; Cc = Cc * albedo;
+                        key = rt_rng_child_key(key, 0u);
+                        depth += 1u;
+                        ray_slot = RT_CNT_RAYS_REFLECTION;
+                    } else if (REFR) {
+                        cnt.add(RT_CNT_REFRACTION);
+                        float kr = rt_fresnel(rd, h.normal, m.refraction_index, m.reflectivity);
+                        f3 fo, fd;
+                        bool has_refr = rt_refraction_ray(rd, h, m.refraction_index, fo, fd);
+                        cnt.add(RT_CNT_REFLECTION_RAY);
+                        f3 lo = h.point + RT_EPSILON * h.normal;
+                        f3 ldv = rt_reflect(rd, h.normal);
+                        f3 p;
+                        if (!dmode) p = shade_lights<EVENTS>(S, rd, h, albedo, m, obj, cnt);
+                        else p = L + m.emission_power * albedo;
+                        f3 cchild = Cc * albedo;
+                        float *f = rfr[depth];
+                        f[12] = kr;
+                        f[13] = __int_as_float(S.objects[obj].material);
+                        f[15] = dmode ? 1.0f : 0.0f;
+                        if (has_refr) {
+                            f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = ldv.x; f[4] = ldv.y; f[5] = ldv.z;
+                            f[6] = p.x; f[7] = p.y; f[8] = p.z; f[9] = cchild.x; f[10] = cchild.y; f[11] = cchild.z;
+                            f[14] = __uint_as_float(rt_rng_child_key(key, 0u));
+                            kinds = (kinds & ~(3ull << (2u * depth))) | ((uint64_t)FK_REFR1 << (2u * depth));
+                            ro = fo; rd = fd; Cc = cchild;  // L unchanged: the refraction child gets the parent's light_color
+                            key = rt_rng_child_key(key, 1u);
+                            dmode = false;                 // the refraction child always runs color()
+                            ray_slot = RT_CNT_RAYS_REFRACTION;
+                        } else {
+                            f[0] = 0.0f; f[1] = 0.0f; f[2] = 0.0f;
+                            kinds = (kinds & ~(3ull << (2u * depth))) | ((uint64_t)FK_REFR2 << (2u * depth));
+                            ro = lo; rd = ldv; L = p; Cc = cchild;
+                            key = rt_rng_child_key(key, 0u);
+                            ray_slot = RT_CNT_RAYS_REFLECTION;
+                        }
+                        depth += 1u;
+                    } else {
+                        V = splat3(0.0f);  // unreachable: REFR is set whenever a refractive material exists
+                        have_value = true;
+                    }
+                }
+            }
+            // ---- unwind: feed V to the pending frames until a second child must be traced or the root returns
+            while (have_value) {
+                if (depth == 0u) { done = true; break; }
+                const uint32_t d = depth - 1u;
+                const uint32_t kind = (uint32_t)(kinds >> (2u * d)) & 3u;
+                if (kind == FK_PASS) { depth = d; continue; }
+                if (kind == FK_REFL) {
+                    const float *fr = s_frames + (size_t)(d * 4u) * nthr + tid;
+                    f3 p = mk3(fr[0], fr[nthr], fr[2u * nthr]);
+                    float rough = fr[3u * nthr];
+                    cnt.add(RT_CNT_COMBINE_REFL);
+                    V = p * rough + p * V * (1.0f - rough);  // ray_tracing.rs:194
+                    depth = d;
+                    continue;
+                }
+                if (REFR) {
+                    float *f = rfr[d];
+                    if (kind == FK_REFR1) {
+                        ro = mk3(f[0], f[1], f[2]); rd = mk3(f[3], f[4], f[5]);
+                        L = mk3(f[6], f[7], f[8]); Cc = mk3(f[9], f[10], f[11]);
+                        key = __float_as_uint(f[14]);
+                        dmode = f[15] != 0.0f;
+                        f[0] = V.x; f[1] = V.y; f[2] = V.z;
+                        kinds = (kinds & ~(3ull << (2u * d))) | ((uint64_t)FK_REFR2 << (2u * d));
+                        ray_slot = RT_CNT_RAYS_REFLECTION;
+                        have_value = false;  // descend into the reflection child at the same depth
+                    } else {
+                        f3 refr = mk3(f[0], f[1], f[2]);
+                        float kr = f[12];
+                        const DevMaterial &dm = S.materials[__float_as_int(f[13])];
+                        cnt.add(RT_CNT_COMBINE_REFR);
+                        f3 col = V * kr + refr * (1.0f - kr) * dm.transparency;  // ray_tracing.rs:232-233 / :150-151
+                        if (f[15] == 0.0f) col = col * ld3(dm.albedo);             // only color() multiplies by albedo (:235)
+                        V = col;
+                        depth = d;
+                    }
+                } else {
+                    depth = d;
+                }
+            }
+        }
+        store_pixel(F, pos, V);
+    }
+    flush_counters<EVENTS>(F, cnt, s_cnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ray marching
+// ------------------------------------------------------------------------------------------------
+struct SdfOut { float dist; f3 albedo, tro, trd; };
+
+RT_DEV float rt_mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }                       // geometry.rs:34-36
+RT_DEV float rt_interpolation(float d1, float d2, float k) { return rt_clamp(0.5f + 0.5f * (d2 - d1) / k, 0.0f, 1.0f); }  // :42-44
+RT_DEV float rt_smooth_union(float d1, float d2, float k) {                                             // :46-50
+    float h = rt_clamp(0.5f + 0.5f * (d2 - d1) / k, 0.0f, 1.0f);
+    return rt_mix(d2, d1, h) - k * h * (1.0f - h);
+}
+RT_DEV float rt_smooth_step(float e0, float e1, float x) {  // :29-32
+    float t = rt_clamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+// Object3D::sdf (src/objects.rs:33-44).  FULL: also albedo and transformed_ray (needed at the final march
+// step only); LEVEL: remaining Union/Substraction nesting the instantiation can descend.
+template <bool EVENTS, bool FULL, int LEVEL>
+struct Sdf {
+    static RT_DEV void eval(const DevScene &S, const DevObject &o, f3 ro, f3 rd, float t, SdfOut &out, Cnt<EVENTS> &cnt) {
+        switch (o.kind) {
+            case RT_SPHERE: {  // sphere.rs:72-82
+                cnt.add(RT_CNT_SDF_SPHERE);
+                f3 trd = xf_dir(o.inv, rd), tro = xf_pt(o.inv, ro);
+                f3 p = tro + trd * t;
+                out.dist = length(p) - o.p[0];
+                if (FULL) { out.albedo = ld3(S.materials[o.material].albedo); out.tro = tro; out.trd = trd; }
+                break;
+            }
+            case RT_CUBOID: {  // cuboid.rs:53-70
+                cnt.add(RT_CNT_SDF_CUBOID);
+                f3 trd = xf_dir(o.inv, rd), tro = xf_pt(o.inv, ro);
+                f3 p = tro + trd * t;
+                const float corner_radius = 0.1f;
+                f3 q = vabs(p) - ld3(o.p) + corner_radius;
+                out.dist = length(vmax(q, splat3(0.0f))) + rt_min(rt_max(q.x, rt_max(q.y, q.z)), 0.0f) - corner_radius;
+                if (FULL) { out.albedo = ld3(S.materials[o.material].albedo); out.tro = tro; out.trd = trd; }
+                break;
+            }
+            case RT_PLANE: {  // plane.rs:31-37
+                cnt.add(RT_CNT_SDF_PLANE);
+                f3 p = ro + rd * t;
+                out.dist = dot(p - ld3(o.p + 3), ld3(o.p));
+                if (FULL) { out.albedo = ld3(S.materials[o.material].albedo); out.tro = ro; out.trd = rd; }
+                break;
+            }
+            case RT_CYLINDER: {  // cylinder.rs:56-74
+                cnt.add(RT_CNT_SDF_CYLINDER);
+                f3 trd = xf_dir(o.inv, rd), tro = xf_pt(o.inv, ro);
+                f3 p = tro + trd * t;
+                const float corner_radius = 0.1f;
+                float dx = (rt_sqrt((p.x * p.x) + (p.z * p.z)) - o.p[0]) + corner_radius;
+                float dy = (rt_abs(p.y) - o.p[1] * 0.5f) + corner_radius;
+                float mx = rt_max(dx, 0.0f), my = rt_max(dy, 0.0f);
+                out.dist = rt_sqrt((mx * mx) + (my * my)) + rt_min(rt_max(dx, dy), 0.0f) - corner_radius;
+                if (FULL) { out.albedo = ld3(S.materials[o.material].albedo); out.tro = tro; out.trd = trd; }
+                break;
+            }
+            case RT_UNION: {  // union.rs:26-42
+                if constexpr (LEVEL > 0) {
+                    cnt.add(RT_CNT_SDF_UNION);
+                    SdfOut h1, h2;
+                    Sdf<EVENTS, FULL, LEVEL - 1>::eval(S, S.objects[o.first], ro, rd, t, h1, cnt);
+                    Sdf<EVENTS, FULL, LEVEL - 1>::eval(S, S.objects[o.second], ro, rd, t, h2, cnt);
+                    out.dist = rt_smooth_union(h1.dist, h2.dist, 0.7f);
+                    if (FULL) {
+                        float i = rt_interpolation(h1.dist, h2.dist, 0.7f);
+                        float a = 1.0f - i;
+                        out.albedo = h1.albedo * (1.0f - a) + h2.albedo * a;  // mix_vec3, geometry.rs:38-40
+                        if (h1.dist < h2.dist) { out.tro = h1.tro; out.trd = h1.trd; } else { out.tro = h2.tro; out.trd = h2.trd; }
+                    }
+                } else {
+                    out.dist = RT_F32_MAX; if (FULL) { out.albedo = splat3(0.0f); out.tro = splat3(0.0f); out.trd = splat3(0.0f); }
+                }
+                break;
+            }
+            case RT_SUBSTRACTION: {  // substraction.rs:26-37
+                if constexpr (LEVEL > 0) {
+                    cnt.add(RT_CNT_SDF_SUBSTRACTION);
+                    SdfOut h1, h2;
+                    const DevObject &o1 = S.objects[o.first];
+                    Sdf<EVENTS, FULL, LEVEL - 1>::eval(S, o1, ro, rd, t, h1, cnt);
+                    Sdf<EVENTS, FULL, LEVEL - 1>::eval(S, S.objects[o.second], ro, rd, t, h2, cnt);
+                    out.dist = rt_max(-h2.dist, h1.dist);
+                    if (FULL) { out.albedo = ld3(S.materials[o1.material].albedo); out.tro = h2.tro; out.trd = h2.trd; }
+                } else {
+                    out.dist = RT_F32_MAX; if (FULL) { out.albedo = splat3(0.0f); out.tro = splat3(0.0f); out.trd = splat3(0.0f); }
+                }
+                break;
+            }
+            default:  // cone.rs:55-57, triangle.rs:29-31
+                out.dist = RT_F32_MAX;
+                if (FULL) { out.albedo = splat3(0.0f); out.tro = splat3(0.0f); out.trd = splat3(0.0f); }
+                break;
+        }
+    }
+};
+
+// RayMarching::sdfs (src/ray_marching/ray_marching.rs:24-107); returns obj_idx
+template <bool EVENTS, bool FULL>
+RT_DEV uint32_t rm_sdfs(const DevScene &S, f3 ro, f3 rd, float t, SdfOut &best, Cnt<EVENTS> &cnt) {
+    cnt.add(RT_CNT_SDFS_CALL);
+    best.dist = RT_F32_MAX;
+    best.albedo = splat3(0.0f); best.tro = splat3(0.0f); best.trd = splat3(0.0f);
+    uint32_t obj_idx = 0u;
+    const uint32_t n = S.n_sdfs;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t idx = S.sdfs[k];
+        const DevObject &o = S.objects[idx];
+        const int kind = o.kind;
+        if (kind == RT_TRIANGLE || kind == RT_CONE) continue;  // the `_ => {}` arm (:95)
+        SdfOut d;
+        Sdf<EVENTS, FULL, 2>::eval(S, o, ro, rd, t, d, cnt);
+        if (d.dist < best.dist) {
+            best.dist = d.dist;
+            if (FULL) { best.albedo = d.albedo; best.tro = d.tro; best.trd = d.trd; }
+            obj_idx = (kind == RT_UNION || kind == RT_SUBSTRACTION) ? (uint32_t)o.second : idx;
+        }
+    }
+    return obj_idx;
+}
+
+template <bool EVENTS>
+__global__ void __launch_bounds__(256) rt_march_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
+    __shared__ uint32_t s_cnt[(EVENTS ? RT_CNT_COUNT : 0) + 1];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)((EVENTS ? RT_CNT_COUNT : 0) + 1); i += blockDim.x) s_cnt[i] = 0u;
+    __syncthreads();
+    Cnt<EVENTS> cnt;
+    cnt.clear();
+    Cnt<false> nocnt;
+    nocnt.clear();
+    uint32_t px, py;
+    if (lane_pixel(C, F, px, py)) {
+        const uint32_t pos = py * C.width + px;
+        cnt.add(RT_CNT_RAYGEN);
+        cnt.add(RT_CNT_PIXEL_PACK);
+        const f3 ro = ld3(C.position);
+        const f3 rd = camera_ray(C, px, py);
+        f3 color = ld3(S.ambient);  // miss: ambient_color, no fade (:252)
+        // march_ray (:181-203)
+        cnt.ray(RT_CNT_RAYS_MARCH);
+        float t = 0.0f, t_eval = 0.0f;
+        bool hit = false;
+        for (int i = 0; i < 255; i++) {
+            if (t > 40.0f) break;
+            cnt.add(RT_CNT_MARCH_STEP);
+            SdfOut d;
+            rm_sdfs<EVENTS, false>(S, ro, rd, t, d, cnt);
+            t_eval = t;
+            t = t + d.dist;
+            if (d.dist < 0.001f) { hit = true; break; }
+        }
+        if (hit) {
+            cnt.add(RT_CNT_MARCH_SHADE);
+            // the final step again with albedo / transformed_ray / object index (same inputs, same values)
+            SdfOut rh;
+            const uint32_t obj_idx = rm_sdfs<false, true>(S, ro, rd, t_eval, rh, nocnt);
+            const float distance = t;
+            f3 hitp = ro + rd * distance;
+            // normal (:109-139)
+            const float k = 0.5773f * 0.0005f;
+            const f3 xyy = mk3(1.0f, -1.0f, -1.0f), yyx = mk3(-1.0f, -1.0f, 1.0f), yxy = mk3(-1.0f, 1.0f, -1.0f), xxx = mk3(1.0f, 1.0f, 1.0f);
+            SdfOut a, b, c, d4;
+            rm_sdfs<EVENTS, false>(S, hitp, xyy, k, a, cnt);
+            rm_sdfs<EVENTS, false>(S, hitp, yyx, k, b, cnt);
+            rm_sdfs<EVENTS, false>(S, hitp, yxy, k, c, cnt);
+            rm_sdfs<EVENTS, false>(S, hitp, xxx, k, d4, cnt);
+            f3 n = normalize(xyy * a.dist + yyx * b.dist + yxy * c.dist + xxx * d4.dist);
+            // material of the winning object (:212-214); the index differs per lane: vector loads
+            const DevObject *po = S.objects + obj_idx;
+            const int okind = po->kind;
+            const int mat_idx = (okind == RT_UNION || okind == RT_SUBSTRACTION) ? 0 : po->material;
+            Mtl m = load_mtl(S.materials[mat_idx]);
+            f3 albedo = rh.albedo;
+            if (m.texture >= 0) {  // tri-planar (:218-232, geometry.rs:56-68)
+                cnt.add(RT_CNT_TRIPLANAR);
+                DevXform inv = po->inv;
+                f3 n1 = normalize(xf_dir(inv, n));
+                f3 hit1 = rh.tro + rh.trd * distance;
+                const DevTexture tex = S.textures[m.texture];
+                const float scale = 0.5f;
+                f3 tx = tex_from_uv(tex, hit1.y * scale, hit1.z * scale);
+                f3 ty = tex_from_uv(tex, hit1.x * scale, hit1.z * scale);
+                f3 tz = tex_from_uv(tex, hit1.x * scale, hit1.y * scale);
+                f3 bw = vpowf(vabs(n1), 0.8f);
+                bw = bw / (bw.x + bw.y + bw.z);
+                albedo = tx * bw.x + ty * bw.y + tz * bw.z;
+            }
+            // light (:160-179)
+            cnt.add(RT_CNT_LIGHT_CALL);
+            f3 l_acc = splat3(0.0f);
+            for (uint32_t i = 0; i < S.n_lights; i++) {
+                const DevLight &l = S.lights[i];
+                cnt.add(RT_CNT_LIGHT_SHADE);
+                f3 ldir; float ldist;
+                light_dir_dist(l, hitp, ldir, ldist);
+                f3 phong = blinn_phong(rd, n, ldir, albedo, m);
+                l_acc = l_acc + (phong / (ldist * ldist)) * ld3(l.albedo) * l.intensity;
+            }
+            color = vpowf(l_acc, 0.4545f);
+            // occlusion (:141-158)
+            float occ = 0.0f, sca = 1.0f;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                cnt.add(RT_CNT_OCCLUSION_TAP);
+                float hr = 0.02f + 0.025f * (float)(i * i);
+                SdfOut dd;
+                rm_sdfs<EVENTS, false>(S, hitp, n, hr, dd, cnt);
+                occ = occ + (-(dd.dist - hr)) * sca;
+                sca = sca * 0.85f;
+            }
+            float o = 1.0f - rt_clamp(occ, 0.0f, 1.0f);
+            color = color * o;
+            color = color * (1.0f - rt_smooth_step(1.0f, 20.0f, distance));
+        }
+        store_pixel(F, pos, color);
+    }
+    flush_counters<EVENTS>(F, cnt, s_cnt);
+}

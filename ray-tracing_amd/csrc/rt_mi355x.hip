@@ -1,0 +1,441 @@
+// rt_mi355x.hip — host runtime behind the C ABI of include/rt_mi355x.h: owns the device copy of
+// Scene / Camera / frame buffers and launches the gfx950 kernels of rt_kernels.h.
+//
+// What it replaces in the reference: the body of Renderer::render between the reset-on-update and the
+// texture upload (src/renderer.rs:104-143), plus Camera::calculate_ray_directions (src/camera.rs:128-157),
+// which the kernels fold into ray generation.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+#include "rt_bvh.h"
+#include "rt_dev_scene.h"
+#include "rt_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr uint32_t kMaxTextures = 64;
+constexpr uint32_t kMaxBounces = 32;  // capacity of the per-lane frame storage
+constexpr uint32_t kMaxCompositeDepth = 2;
+
+template <typename T>
+struct DevBuf {
+    T *ptr = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+        hipError_t e = hipMalloc((void **)&ptr, n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evc0 = nullptr, evc1 = nullptr;
+    std::string err;
+
+    DevBuf<DevObject> objects;
+    DevBuf<DevMaterial> materials;
+    DevBuf<DevLight> lights;
+    DevBuf<uint32_t> sdfs;
+    DevBuf<DevTexture> textures;
+    DevBuf<DevBvhNode> bvh_nodes;
+    DevBuf<uint32_t> bvh_prims;
+    DevBuf<uint32_t> tex_data[kMaxTextures];
+    DevTexture h_textures[kMaxTextures] = {};
+    std::vector<int32_t> mat_texture;  // texture index of every material, for the render-time check
+
+    DevScene scene = {};
+    DevCamera camera = {};
+    bool has_scene = false, has_camera = false, has_refractive = false;
+
+    DevBuf<uint32_t> rgba;
+    DevBuf<float> accum;
+    DevBuf<uint32_t> counters;
+    std::vector<uint32_t> h_counters;
+    uint32_t last_blocks = 0, last_ncnt = 0;
+    bool last_events = false, timed = false;
+    hipStream_t last_stream = nullptr;
+    double last_copy_ms = 0.0;
+    uint64_t frames = 0;
+};
+
+namespace {
+
+int32_t fail(rt_ctx *c, rt_status st, const std::string &msg) {
+    if (c) c->err = msg;
+    return (int32_t)st;
+}
+#define RT_HIP(ctx, call)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) return fail(ctx, RT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// columns of a glam Mat4 (xyz rows) + the `column 3 times 0.0` term of a direction transform
+DevXform make_xform(const float *m) {
+    DevXform x;
+    for (int r = 0; r < 3; r++) {
+        x.c0[r] = m[r]; x.c1[r] = m[4 + r]; x.c2[r] = m[8 + r]; x.c3[r] = m[12 + r];
+        x.z[r] = m[12 + r] * 0.0f;
+    }
+    return x;
+}
+
+int composite_depth(const rt_scene_desc *d, uint32_t i, int guard) {
+    if (i >= d->n_objects || guard > 8) return -1;
+    const rt_object &o = d->objects[i];
+    if (o.kind != RT_UNION && o.kind != RT_SUBSTRACTION) return 0;
+    if (o.first < 0 || o.second < 0) return -1;
+    int a = composite_depth(d, (uint32_t)o.first, guard + 1), b = composite_depth(d, (uint32_t)o.second, guard + 1);
+    if (a < 0 || b < 0) return -1;
+    return 1 + (a > b ? a : b);
+}
+
+template <typename K>
+void launch(K kernel, uint32_t blocks, uint32_t threads, size_t lds, hipStream_t s, const DevScene &S, const DevCamera &C, const DevFrame &F) {
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, s, S, C, F);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+
+const char *rt_last_error(rt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int32_t rt_create(int32_t device_id, rt_ctx **out) {
+    if (!out) return RT_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return RT_ERR_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return RT_ERR_DEVICE;
+    rt_ctx *c = new rt_ctx();
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->evc0) != hipSuccess || hipEventCreate(&c->evc1) != hipSuccess ||
+        c->textures.ensure(kMaxTextures) != hipSuccess) {
+        rt_destroy(c);
+        return RT_ERR_DEVICE;
+    }
+    (void)hipMemset(c->textures.ptr, 0, kMaxTextures * sizeof(DevTexture));
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->objects.release(); c->materials.release(); c->lights.release(); c->sdfs.release(); c->textures.release();
+    c->bvh_nodes.release(); c->bvh_prims.release();
+    for (auto &t : c->tex_data) t.release();
+    c->rgba.release(); c->accum.release(); c->counters.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->evc0) (void)hipEventDestroy(c->evc0);
+    if (c->evc1) (void)hipEventDestroy(c->evc1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!d) return fail(c, RT_ERR_INVALID_ARGUMENT, "scene is null");
+    if ((d->n_objects && !d->objects) || (d->n_materials && !d->materials) || (d->n_lights && !d->lights) || (d->n_sdfs && !d->sdfs))
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "scene array pointer is null");
+    if (d->n_textures > kMaxTextures) return fail(c, RT_ERR_UNSUPPORTED, "more than 64 texture slots");
+    if (d->max_ray_bounces > kMaxBounces) return fail(c, RT_ERR_UNSUPPORTED, "max_ray_bounces above 32");
+    // what the reference would panic on (index out of bounds), checked up front
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const rt_material &m = d->materials[i];
+        if (m.kind != RT_REFLECTIVE && m.kind != RT_REFRACTIVE) return fail(c, RT_ERR_INVALID_ARGUMENT, "material " + std::to_string(i) + ": unknown kind");
+        if (m.texture < -1 || (m.texture >= 0 && (uint32_t)m.texture >= d->n_textures))
+            return fail(c, RT_ERR_INVALID_ARGUMENT, "material " + std::to_string(i) + ": texture index out of range");
+    }
+    for (uint32_t i = 0; i < d->n_objects; i++) {
+        const rt_object &o = d->objects[i];
+        if (o.kind < RT_SPHERE || o.kind > RT_SUBSTRACTION) return fail(c, RT_ERR_INVALID_ARGUMENT, "object " + std::to_string(i) + ": unknown kind");
+        if (o.kind == RT_UNION || o.kind == RT_SUBSTRACTION) {
+            int depth = composite_depth(d, i, 0);
+            if (depth < 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "object " + std::to_string(i) + ": child index out of range or cyclic");
+            if ((uint32_t)depth > kMaxCompositeDepth) return fail(c, RT_ERR_UNSUPPORTED, "object " + std::to_string(i) + ": Union/Substraction nested deeper than 2");
+        } else if (o.material_index < 0 || (uint32_t)o.material_index >= d->n_materials) {
+            return fail(c, RT_ERR_INVALID_ARGUMENT, "object " + std::to_string(i) + ": material index out of range");
+        }
+    }
+    for (uint32_t i = 0; i < d->n_sdfs; i++)
+        if (d->sdfs[i] >= d->n_objects) return fail(c, RT_ERR_INVALID_ARGUMENT, "sdfs[" + std::to_string(i) + "] out of range");
+    for (uint32_t i = 0; i < d->n_lights; i++)
+        if (d->lights[i].kind < RT_DIRECTIONAL || d->lights[i].kind > RT_SPHERICAL_POSITIONAL) return fail(c, RT_ERR_INVALID_ARGUMENT, "light " + std::to_string(i) + ": unknown kind");
+    if (d->ray_marching && d->n_sdfs > 0 && d->n_materials == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "ray marching scene without materials");
+
+    RT_HIP(c, hipSetDevice(c->device));
+    std::vector<DevObject> objs(d->n_objects);
+    for (uint32_t i = 0; i < d->n_objects; i++) {
+        const rt_object &o = d->objects[i];
+        DevObject &g = objs[i];
+        std::memset(&g, 0, sizeof(g));
+        g.kind = o.kind;
+        g.material = (o.kind == RT_UNION || o.kind == RT_SUBSTRACTION) ? 0 : o.material_index;
+        g.first = o.first; g.second = o.second;
+        g.inv = make_xform(o.inv_transform);
+        g.fwd = make_xform(o.transform);
+        switch (o.kind) {
+            case RT_SPHERE: g.p[0] = o.radius; break;
+            case RT_CUBOID:
+                for (int k = 0; k < 3; k++) {
+                    g.p[k] = o.dimension[k];
+                    // b_min / b_max = (Mat4::from_scale(dimension) * vec4(-+1, -+1, -+1, 0)).xyz (src/utils/cuboid.rs:48-49)
+                    float col[3] = {0.0f, 0.0f, 0.0f};
+                    col[k] = o.dimension[k];
+                    g.p[3 + k] = ((col[0] * -1.0f + col[1] * -1.0f) + col[2] * -1.0f) + 0.0f * 0.0f;
+                    g.p[6 + k] = ((col[0] * 1.0f + col[1] * 1.0f) + col[2] * 1.0f) + 0.0f * 0.0f;
+                }
+                break;
+            case RT_PLANE:
+                for (int k = 0; k < 3; k++) { g.p[k] = o.normal[k]; g.p[3 + k] = o.point[k]; }
+                g.p[6] = o.max_dist[0]; g.p[7] = o.max_dist[1]; g.p[8] = o.has_max_dist ? 1.0f : 0.0f;
+                break;
+            case RT_CYLINDER: g.p[0] = o.radius; g.p[1] = o.height; break;
+            case RT_TRIANGLE:
+                for (int k = 0; k < 3; k++) { g.p[k] = o.v1[k]; g.p[3 + k] = o.v2[k]; g.p[6 + k] = o.v3[k]; }
+                break;
+            default: break;
+        }
+    }
+    std::vector<DevMaterial> mats(d->n_materials);
+    c->mat_texture.assign(d->n_materials, -1);
+    c->has_refractive = false;
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const rt_material &m = d->materials[i];
+        DevMaterial &g = mats[i];
+        std::memset(&g, 0, sizeof(g));
+        g.ambience = m.ambience; g.diffuse = m.diffuse; g.specular = m.specular; g.shininess = m.shininess;
+        for (int k = 0; k < 3; k++) g.albedo[k] = m.albedo[k];
+        g.texture = m.texture; g.kind = m.kind; g.roughness = m.roughness; g.transparency = m.transparency;
+        g.refraction_index = m.refraction_index; g.reflectivity = m.reflectivity; g.emission_power = m.emission_power;
+        c->mat_texture[i] = m.texture;
+        if (m.kind == RT_REFRACTIVE) c->has_refractive = true;
+    }
+    std::vector<DevLight> lights(d->n_lights);
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+        const rt_light &l = d->lights[i];
+        DevLight &g = lights[i];
+        g.kind = l.kind; g.intensity = l.intensity;
+        for (int k = 0; k < 3; k++) { g.albedo[k] = l.albedo[k]; g.vec[k] = l.vec[k]; }
+    }
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, c->objects.ensure(objs.size() ? objs.size() : 1));
+    RT_HIP(c, c->materials.ensure(mats.size() ? mats.size() : 1));
+    RT_HIP(c, c->lights.ensure(lights.size() ? lights.size() : 1));
+    RT_HIP(c, c->sdfs.ensure(d->n_sdfs ? d->n_sdfs : 1));
+    if (!objs.empty()) RT_HIP(c, hipMemcpy(c->objects.ptr, objs.data(), objs.size() * sizeof(DevObject), hipMemcpyHostToDevice));
+    if (!mats.empty()) RT_HIP(c, hipMemcpy(c->materials.ptr, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
+    if (!lights.empty()) RT_HIP(c, hipMemcpy(c->lights.ptr, lights.data(), lights.size() * sizeof(DevLight), hipMemcpyHostToDevice));
+    if (d->n_sdfs) RT_HIP(c, hipMemcpy(c->sdfs.ptr, d->sdfs, d->n_sdfs * sizeof(uint32_t), hipMemcpyHostToDevice));
+
+    DevScene &S = c->scene;
+    std::memset(&S, 0, sizeof(S));
+    S.objects = c->objects.ptr; S.materials = c->materials.ptr; S.lights = c->lights.ptr; S.sdfs = c->sdfs.ptr;
+    S.textures = c->textures.ptr;
+    S.n_objects = d->n_objects; S.n_materials = d->n_materials; S.n_lights = d->n_lights; S.n_sdfs = d->n_sdfs;
+    for (int k = 0; k < 3; k++) S.ambient[k] = d->ambient_color[k];
+    S.max_ray_bounces = d->max_ray_bounces; S.shadow_casting = d->shadow_casting; S.ray_marching = d->ray_marching;
+    S.diffuse = d->diffuse; S.enable_accumulation = d->enable_accumulation;
+
+    // Large all-sphere scenes get a bounding-volume hierarchy; small or mixed scenes keep the reference's linear scan.
+    S.bvh_nodes = nullptr; S.bvh_prims = nullptr;
+    if (!d->ray_marching && rt_bvh_wanted(d)) {
+        std::vector<DevBvhNode> nodes; std::vector<uint32_t> prims;
+        rt_bvh_build(d, nodes, prims);
+        RT_HIP(c, c->bvh_nodes.ensure(nodes.size()));
+        RT_HIP(c, c->bvh_prims.ensure(prims.size()));
+        RT_HIP(c, hipMemcpy(c->bvh_nodes.ptr, nodes.data(), nodes.size() * sizeof(DevBvhNode), hipMemcpyHostToDevice));
+        RT_HIP(c, hipMemcpy(c->bvh_prims.ptr, prims.data(), prims.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        S.bvh_nodes = c->bvh_nodes.ptr; S.bvh_prims = c->bvh_prims.ptr;
+    }
+    c->has_scene = true;
+    return RT_OK;
+}
+
+int32_t rt_set_texture(rt_ctx *c, uint32_t index, uint32_t width, uint32_t height, const uint8_t *rgb8) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (index >= kMaxTextures) return fail(c, RT_ERR_UNSUPPORTED, "texture slot above 63");
+    if (!rgb8 || width == 0 || height == 0 || width > 32768 || height > 32768) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad texture arguments");
+    RT_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)width * height;
+    std::vector<uint32_t> packed(n);
+    for (size_t i = 0; i < n; i++) packed[i] = (uint32_t)rgb8[3 * i] | ((uint32_t)rgb8[3 * i + 1] << 8) | ((uint32_t)rgb8[3 * i + 2] << 16);
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, c->tex_data[index].ensure(n));
+    RT_HIP(c, hipMemcpy(c->tex_data[index].ptr, packed.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->h_textures[index].texels = c->tex_data[index].ptr;
+    c->h_textures[index].width = width;
+    c->h_textures[index].height = height;
+    RT_HIP(c, hipMemcpy(c->textures.ptr + index, &c->h_textures[index], sizeof(DevTexture), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int32_t rt_set_camera(rt_ctx *c, const rt_camera_desc *cam) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!cam || cam->width == 0 || cam->height == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad camera");
+    if ((uint64_t)cam->width * cam->height > (1ull << 31)) return fail(c, RT_ERR_UNSUPPORTED, "frame above 2^31 pixels");
+    RT_HIP(c, hipSetDevice(c->device));
+    DevCamera &C = c->camera;
+    for (int r = 0; r < 4; r++) {
+        C.ip_c0[r] = cam->inverse_perspective[r]; C.ip_c1[r] = cam->inverse_perspective[4 + r];
+        C.ip_c2[r] = cam->inverse_perspective[8 + r]; C.ip_c3[r] = cam->inverse_perspective[12 + r];
+    }
+    C.iv = make_xform(cam->inverse_view);
+    for (int k = 0; k < 3; k++) C.position[k] = cam->position[k];
+    const size_t px = (size_t)cam->width * cam->height;
+    if (px != (size_t)C.width * C.height || !c->rgba.ptr) {
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+        RT_HIP(c, c->rgba.ensure(px));
+        RT_HIP(c, c->accum.ensure(px * 4));
+        RT_HIP(c, hipMemsetAsync(c->accum.ptr, 0, px * 4 * sizeof(float), c->stream));
+    }
+    C.width = cam->width; C.height = cam->height;
+    C.inv_w = 1.0f / (float)cam->width;
+    C.inv_h = 1.0f / (float)cam->height;
+    c->has_camera = true;
+    return RT_OK;
+}
+
+int32_t rt_reset_accum(rt_ctx *c) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!c->has_camera) return fail(c, RT_ERR_STATE, "camera not set");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipMemsetAsync(c->accum.ptr, 0, (size_t)c->camera.width * c->camera.height * 4 * sizeof(float), c->stream));
+    return RT_OK;
+}
+
+int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d_accum, void *stream) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!p) return fail(c, RT_ERR_INVALID_ARGUMENT, "params is null");
+    if (!c->has_scene || !c->has_camera) return fail(c, RT_ERR_STATE, "scene or camera not set");
+    if (p->frame_index == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "frame_index must be >= 1");
+    uint32_t rb = p->row_begin, re = p->row_end;
+    if (rb == 0 && re == 0) re = c->camera.height;
+    if (re > c->camera.height || rb >= re) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad row range");
+    for (size_t i = 0; i < c->mat_texture.size(); i++) {
+        int32_t t = c->mat_texture[i];
+        if (t >= 0 && !c->h_textures[t].texels) return fail(c, RT_ERR_STATE, "material " + std::to_string(i) + " uses texture " + std::to_string(t) + " which was never set");
+    }
+    RT_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+
+    const DevScene &S = c->scene;
+    const bool events = p->collect_events != 0;
+    const uint32_t maxd = S.max_ray_bounces;
+    // 256-thread workgroups keep max_ray_bounces * 4 KiB of reflective frames in LDS; deeper recursions use one wave per workgroup
+    const uint32_t threads = (maxd <= 8u) ? 256u : 64u;
+    const uint32_t waves_per_block = threads / 64u;
+    const uint32_t tiles_x = (c->camera.width + 7u) / 8u, tiles_y = (re - rb + 7u) / 8u;
+    const uint64_t n_waves = (uint64_t)tiles_x * tiles_y;
+    const uint32_t blocks = (uint32_t)((n_waves + waves_per_block - 1) / waves_per_block);
+    const uint32_t ncnt = (events ? (uint32_t)RT_CNT_COUNT : 0u) + 1u;
+    RT_HIP(c, c->counters.ensure((size_t)blocks * ncnt));
+
+    DevFrame F;
+    F.frame_index = p->frame_index; F.row_begin = rb; F.row_end = re; F.accumulate = p->accumulate; F.seed = p->seed;
+    F.rgba = d_rgba8 ? (uint32_t *)d_rgba8 : c->rgba.ptr;
+    F.accum = d_accum ? (float *)d_accum : c->accum.ptr;
+    F.counters = c->counters.ptr;
+
+    RT_HIP(c, hipEventRecord(c->ev0, s));
+    if (S.ray_marching) {
+        if (events) launch(rt_march_kernel<true>, blocks, threads, 0, s, S, c->camera, F);
+        else launch(rt_march_kernel<false>, blocks, threads, 0, s, S, c->camera, F);
+    } else {
+        const size_t lds = (size_t)(maxd ? maxd : 1u) * 4u * threads * sizeof(float);
+        const bool refr = c->has_refractive;
+        if (!refr) {
+            if (events) launch(rt_trace_kernel<true, false, 1>, blocks, threads, lds, s, S, c->camera, F);
+            else launch(rt_trace_kernel<false, false, 1>, blocks, threads, lds, s, S, c->camera, F);
+        } else if (maxd <= 8u) {
+            if (events) launch(rt_trace_kernel<true, true, 8>, blocks, threads, lds, s, S, c->camera, F);
+            else launch(rt_trace_kernel<false, true, 8>, blocks, threads, lds, s, S, c->camera, F);
+        } else {
+            if (events) launch(rt_trace_kernel<true, true, 32>, blocks, threads, lds, s, S, c->camera, F);
+            else launch(rt_trace_kernel<false, true, 32>, blocks, threads, lds, s, S, c->camera, F);
+        }
+    }
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipEventRecord(c->ev1, s));
+    c->last_blocks = blocks; c->last_ncnt = ncnt; c->last_events = events; c->timed = true; c->last_stream = s;
+    c->frames += 1;
+    return RT_OK;
+}
+
+int32_t rt_render(rt_ctx *c, uint32_t frame_index, int32_t accumulate, int32_t reset_accum, uint64_t seed, uint8_t *out, size_t out_len) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!c->has_scene || !c->has_camera) return fail(c, RT_ERR_STATE, "scene or camera not set");
+    const size_t need = (size_t)c->camera.width * c->camera.height * 4;
+    if (!out || out_len != need) return fail(c, RT_ERR_INVALID_ARGUMENT, "out_rgba8 must hold width*height*4 bytes");
+    if (reset_accum) { int32_t r = rt_reset_accum(c); if (r != RT_OK) return r; }
+    rt_render_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.frame_index = frame_index; p.accumulate = accumulate; p.seed = seed;
+    int32_t r = rt_render_device(c, &p, nullptr, nullptr, nullptr);
+    if (r != RT_OK) return r;
+    RT_HIP(c, hipEventRecord(c->evc0, c->stream));
+    RT_HIP(c, hipMemcpyAsync(out, c->rgba.ptr, need, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipEventRecord(c->evc1, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->evc0, c->evc1) == hipSuccess) c->last_copy_ms = ms;
+    return RT_OK;
+}
+
+int32_t rt_read_accum(rt_ctx *c, float *out, size_t n_vec4) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!c->has_camera) return fail(c, RT_ERR_STATE, "camera not set");
+    if (!out || n_vec4 != (size_t)c->camera.width * c->camera.height) return fail(c, RT_ERR_INVALID_ARGUMENT, "out must hold width*height float4");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpy(out, c->accum.ptr, n_vec4 * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int32_t rt_get_stats(rt_ctx *c, rt_stats *out) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!out) return fail(c, RT_ERR_INVALID_ARGUMENT, "out is null");
+    std::memset(out, 0, sizeof(*out));
+    RT_HIP(c, hipSetDevice(c->device));
+    if (c->timed) {
+        RT_HIP(c, hipStreamSynchronize(c->last_stream));
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) out->last_kernel_ms = ms;
+        const size_t n = (size_t)c->last_blocks * c->last_ncnt;
+        c->h_counters.resize(n);
+        RT_HIP(c, hipMemcpy(c->h_counters.data(), c->counters.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t b = 0; b < c->last_blocks; b++) {
+            const uint32_t *row = c->h_counters.data() + (size_t)b * c->last_ncnt;
+            out->rays_total += row[0];
+            if (c->last_events) for (uint32_t i = 0; i < (uint32_t)RT_CNT_COUNT; i++) out->counters[i] += row[1 + i];
+        }
+    }
+    out->last_copy_ms = c->last_copy_ms;
+    out->frames_rendered = c->frames;
+    return RT_OK;
+}
+
+void *rt_device_rgba8(rt_ctx *c) { return c ? (void *)c->rgba.ptr : nullptr; }
+void *rt_device_accum(rt_ctx *c) { return c ? (void *)c->accum.ptr : nullptr; }
+
+}  // extern "C"
