@@ -49,9 +49,11 @@ def load(host_libm: bool = False) -> C.CDLL:
     return _libs[name]
 
 
-def texture_array(textures):
-    """(ctypes array of orc_texture, keep-alive list) from a list of (h, w, 3) uint8 arrays."""
-    arr = (orc_texture * max(len(textures), 1))()
+def texture_array(textures, n_slots=0):
+    """(ctypes array of orc_texture, keep-alive list) from a list of (h, w, 3) uint8 arrays.
+
+    The array has at least `n_slots` entries (unset slots are zero: width 0, null bytes)."""
+    arr = (orc_texture * max(len(textures), n_slots, 1))()
     keep = []
     for i, t in enumerate(textures):
         t = np.ascontiguousarray(t, dtype=np.uint8)
@@ -76,7 +78,7 @@ def render(desc, camera, textures=(), frame_index=1, accumulate=False, seed=0x5E
     rgba = np.zeros((h, w, 4), dtype=np.uint8)
     linear = np.zeros((h, w, 4), dtype=np.float32) if want_linear else None
     counters = (C.c_uint64 * 64)() if want_counters else None
-    tex, keep = texture_array(list(textures))
+    tex, keep = texture_array(list(textures), int(desc.n_textures))
     rb, re = rows if rows is not None else (0, 0)
     st = l.orc_render(C.addressof(desc), C.addressof(tex), C.addressof(camera), frame_index, int(accumulate), seed, rb, re,
                       accum.ctypes.data, rgba.ctypes.data, linear.ctypes.data if want_linear else None,
