@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Benchmark of the rendering hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+A step is one frame of the hot path (camera rays -> closest hit -> shading -> bounces -> accumulate/pack) over
+one synthetic camera/scene already resident in HBM.  The default workload is BASELINE.json's configs[1]: the
+reference's default plane+sphere scene (src/bin/scene3.rs) at 3840x2160, 1 spp, max 5 bounces.  The metric is
+Mrays/s, a ray being one trace_ray or march_ray invocation (primary, reflection, refraction, shadow).
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Frames are independent units, so each rank
+renders its own frames of the sequence with no collective in the data path ("weak": per-GPU work is fixed); the
+timing is barrier + synchronize on both sides and the maximum over ranks.  `--shard rows` instead splits every
+frame into row bands (one per rank), and `--shard samples` splits the samples of an accumulated frame and
+all-reduces the accumulators once per step.
+
+Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import __graft_entry__ as graft  # noqa: E402
+
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X: 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz (packed FP32 FMA)
+
+WORKLOADS = {
+    # name: (scene, width, height, max_ray_bounces or None, accumulate, description)
+    "scene3_4k": ("scene3", 3840, 2160, 5, False, "reference default scene (plane + sphere, 2 lights, shadows), 3840x2160, 1 spp, max 5 bounces"),
+    "scene1_4k": ("scene1", 3840, 2160, 5, False, "all-primitives textured scene, 3840x2160, 1 spp, max 5 bounces"),
+    "tex4_4k": ("tex4", 3840, 2160, 5, False, "four textured spheres over a chess plane, 3840x2160, 1 spp, max 5 bounces"),
+    "scene4_4k": ("scene4", 3840, 2160, None, False, "ray-marching SDF scene, 3840x2160, 255 max march steps"),
+    "scene2_4k": ("scene2", 3840, 2160, 5, True, "diffuse emissive path tracing with accumulation, 3840x2160"),
+    "spheres10k_8k": ("spheres10k", 7680, 4320, 5, True, "10 000 diffuse spheres, 7680x4320, accumulated samples"),
+}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="scene3_4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--shard", default="frames", choices=["frames", "rows", "samples"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    pkg = graft.load_package()
+    scene_name, width, height, bounces, accumulate, description = WORKLOADS[args.workload]
+    scene = pkg.Scene(scene_name)
+    if bounces is not None:
+        scene.desc.max_ray_bounces = bounces
+    ctx = pkg.Context(local_rank)
+    ctx.load(scene, width, height)
+
+    rgba = torch.zeros((height, width, 4), dtype=torch.uint8, device="cuda")
+    accum = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream()
+    rows = pkg.shard_rows(height, rank, world) if (args.shard == "rows" and world > 1) else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i: int) -> None:
+        # frames sharded over ranks: rank r renders frames r, r + world, ... of the sequence (sample index when accumulating)
+        frame = 1 + i * world + rank if args.shard != "rows" else 1 + i
+        ctx.render_device(frame_index=frame if accumulate else 1, accumulate=accumulate, seed=0x5EED + frame, rows=rows,
+                          d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=stream.cuda_stream)
+        if args.shard == "samples" and world > 1:
+            dist.all_reduce(accum)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ev1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration on the launch stream (back-to-back launches)
+    rays_rank = ctx.stats()["rays_total"]            # rays of the last frame; deterministic scenes trace the same number every frame
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    r = torch.tensor([float(rays_rank)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+    elapsed_max = float(t.item())
+    rays_per_step_all = float(r.item())
+
+    if rank == 0:
+        # algorithmic FLOPs of one frame: event counts of a (slower, untimed) counting render times the per-event constants
+        ctx.render_device(frame_index=1, accumulate=False, seed=0x5EED + 1, rows=rows, collect_events=True,
+                          d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=stream.cuda_stream)
+        st = ctx.stats()
+        flops = pkg.algorithmic_flops(st)
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        value = rays_per_step_all * args.steps / elapsed_max / 1e6
+        out = {
+            "metric": "Mrays/sec (primary+secondary) and frame ms at 4K",
+            "value": round(value, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak" if args.shard == "frames" else "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {description}", "width": width, "height": height,
+                       "max_ray_bounces": int(scene.desc.max_ray_bounces), "rays_per_frame": int(rays_rank),
+                       "parallelism": f"{args.shard}-sharded x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": None,
+                         "kernel": "rt_march_kernel" if scene.desc.ray_marching else "rt_trace_kernel",
+                         "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
+                         "note": "FP32 vector (VALU) roofline: this path has no dense contraction, so no MFMA"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, scene, width, height, accumulate)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pkg, scene, width, height, accumulate) -> dict:
+    """The CPU restatement of the reference algorithm (oracle/, the reference's 200-chunk decomposition over worker
+    threads) timed on this box's host cores on a bounded sample of the same workload."""
+    orc = graft.load_oracle()
+    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    cam = scene.camera(width, height)
+    tex = scene.textures()
+    # bounded sample: evenly spaced 8-row bands covering ~1/6 of the frame (all of it for cheap scenes), about 10-30 s of core time
+    budget_rows = height if not scene.desc.ray_marching and scene.desc.n_objects < 100 else max(8, height // 48)
+    n_bands = max(1, budget_rows // 8)
+    starts = [int(round(i * (height - 8) / max(1, n_bands - 1))) // 8 * 8 for i in range(n_bands)] if n_bands * 8 < height else None
+    rays = 0
+    t0 = time.perf_counter()
+    if starts is None:
+        r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, want_counters=True)
+        rays = sum(r["counters"][:5])
+        sample = f"1 full {width}x{height} frame"
+    else:
+        for y in sorted(set(starts)):
+            r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, want_counters=True, rows=(y, y + 8))
+            rays += sum(r["counters"][:5])
+        sample = f"{len(set(starts))} evenly spaced 8-row bands of the {width}x{height} frame"
+    dt = time.perf_counter() - t0
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": sample + f", {rays} rays in {dt:.2f} s; CPU restatement of the reference (Rust toolchain unavailable)"}
+
+
+if __name__ == "__main__":
+    main()

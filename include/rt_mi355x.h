@@ -238,8 +238,9 @@ int32_t rt_render(rt_ctx *ctx, uint32_t frame_index, int32_t accumulate, int32_t
 
 /* Same pixel work, device-resident: writes RGBA8 (width*height*4 bytes) to d_rgba8 and the
  * accumulator (width*height float4, Renderer.accumulated) to d_accum, both device pointers owned
- * by the caller; either may be NULL to use the context's own buffers.  `stream` is a hipStream_t
- * (NULL = the context's stream).  Asynchronous: returns after the launch. */
+ * by the caller; either may be NULL to use the context's own buffers.  `stream` is a hipStream_t used
+ * as is (NULL is HIP's default stream; pass rt_context_stream() for the context's own).  Asynchronous:
+ * returns after the launch; the context's other calls wait for it before touching its buffers. */
 int32_t rt_render_device(rt_ctx *ctx, const rt_render_params *params, void *d_rgba8, void *d_accum, void *stream);
 
 /* Zeroes the context's accumulator (Renderer::render on `updated`, src/renderer.rs:93-96). */
@@ -250,6 +251,9 @@ int32_t rt_read_accum(rt_ctx *ctx, float *out_vec4, size_t n_vec4);
 
 /* Waits for the context's stream and sums the per-workgroup counters of the last render. */
 int32_t rt_get_stats(rt_ctx *ctx, rt_stats *out);
+
+/* The hipStream_t the context created for itself (rt_render runs on it).  No counterpart in the reference. */
+void *rt_context_stream(rt_ctx *ctx);
 
 /* Device pointers of the context's own frame buffers (valid until the next rt_set_camera). */
 void *rt_device_rgba8(rt_ctx *ctx);

@@ -120,7 +120,7 @@ class rt_render_params(C.Structure):
 # every symbol include/rt_mi355x.h declares
 ABI_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_texture", "rt_set_camera", "rt_render", "rt_render_device",
-    "rt_reset_accum", "rt_read_accum", "rt_get_stats", "rt_device_rgba8", "rt_device_accum", "rt_last_error",
+    "rt_reset_accum", "rt_read_accum", "rt_get_stats", "rt_context_stream", "rt_device_rgba8", "rt_device_accum", "rt_last_error",
     "rt_abi_version",
 ]
 
@@ -154,6 +154,7 @@ def lib() -> C.CDLL:
         l.rt_reset_accum.argtypes = [vp]; l.rt_reset_accum.restype = C.c_int32
         l.rt_read_accum.argtypes = [vp, C.c_void_p, C.c_size_t]; l.rt_read_accum.restype = C.c_int32
         l.rt_get_stats.argtypes = [vp, C.POINTER(rt_stats)]; l.rt_get_stats.restype = C.c_int32
+        l.rt_context_stream.argtypes = [vp]; l.rt_context_stream.restype = vp
         l.rt_device_rgba8.argtypes = [vp]; l.rt_device_rgba8.restype = vp
         l.rt_device_accum.argtypes = [vp]; l.rt_device_accum.restype = vp
         l.rt_last_error.argtypes = [vp]; l.rt_last_error.restype = C.c_char_p
@@ -303,8 +304,10 @@ class Context:
         return out
 
     def render_device(self, frame_index: int = 1, accumulate: bool = False, seed: int = 0x5EED, rows: Optional[tuple] = None,
-                      collect_events: bool = False, d_rgba8: int = 0, d_accum: int = 0, stream: int = 0):
-        """rt_render_device: asynchronous launch into device buffers (0 = the context's own)."""
+                      collect_events: bool = False, d_rgba8: int = 0, d_accum: int = 0, stream: Optional[int] = None):
+        """rt_render_device: asynchronous launch into device buffers (0 = the context's own).
+
+        `stream` is a hipStream_t handle used as is (0 is HIP's default stream); None selects the context's own stream."""
         p = rt_render_params()
         p.frame_index = frame_index
         p.accumulate = int(accumulate)
@@ -312,6 +315,8 @@ class Context:
         p.seed = seed
         if rows is not None:
             p.row_begin, p.row_end = rows
+        if stream is None:
+            stream = int(self._l.rt_context_stream(self._ctx) or 0)
         self._check(self._l.rt_render_device(self._ctx, C.byref(p), C.c_void_p(d_rgba8 or None), C.c_void_p(d_accum or None),
                                              C.c_void_p(stream or None)), "rt_render_device")
 

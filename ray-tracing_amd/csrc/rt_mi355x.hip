@@ -104,6 +104,13 @@ int composite_depth(const rt_scene_desc *d, uint32_t i, int guard) {
     return 1 + (a > b ? a : b);
 }
 
+// A render may have been launched on a caller's stream; anything that touches the same buffers from another
+// stream waits for it first.
+hipError_t wait_external(rt_ctx *c, hipStream_t next) {
+    if (c->timed && c->last_stream != next) return hipStreamSynchronize(c->last_stream);
+    return hipSuccess;
+}
+
 template <typename K>
 void launch(K kernel, uint32_t blocks, uint32_t threads, size_t lds, hipStream_t s, const DevScene &S, const DevCamera &C, const DevFrame &F) {
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, s, S, C, F);
@@ -238,6 +245,7 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         g.kind = l.kind; g.intensity = l.intensity;
         for (int k = 0; k < 3; k++) { g.albedo[k] = l.albedo[k]; g.vec[k] = l.vec[k]; }
     }
+    RT_HIP(c, wait_external(c, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, c->objects.ensure(objs.size() ? objs.size() : 1));
     RT_HIP(c, c->materials.ensure(mats.size() ? mats.size() : 1));
@@ -280,6 +288,7 @@ int32_t rt_set_texture(rt_ctx *c, uint32_t index, uint32_t width, uint32_t heigh
     const size_t n = (size_t)width * height;
     std::vector<uint32_t> packed(n);
     for (size_t i = 0; i < n; i++) packed[i] = (uint32_t)rgb8[3 * i] | ((uint32_t)rgb8[3 * i + 1] << 8) | ((uint32_t)rgb8[3 * i + 2] << 16);
+    RT_HIP(c, wait_external(c, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, c->tex_data[index].ensure(n));
     RT_HIP(c, hipMemcpy(c->tex_data[index].ptr, packed.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -304,6 +313,7 @@ int32_t rt_set_camera(rt_ctx *c, const rt_camera_desc *cam) {
     for (int k = 0; k < 3; k++) C.position[k] = cam->position[k];
     const size_t px = (size_t)cam->width * cam->height;
     if (px != (size_t)C.width * C.height || !c->rgba.ptr) {
+        RT_HIP(c, wait_external(c, c->stream));
         RT_HIP(c, hipStreamSynchronize(c->stream));
         RT_HIP(c, c->rgba.ensure(px));
         RT_HIP(c, c->accum.ensure(px * 4));
@@ -320,7 +330,9 @@ int32_t rt_reset_accum(rt_ctx *c) {
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!c->has_camera) return fail(c, RT_ERR_STATE, "camera not set");
     RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, wait_external(c, c->stream));
     RT_HIP(c, hipMemsetAsync(c->accum.ptr, 0, (size_t)c->camera.width * c->camera.height * 4 * sizeof(float), c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 
@@ -337,7 +349,8 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
         if (t >= 0 && !c->h_textures[t].texels) return fail(c, RT_ERR_STATE, "material " + std::to_string(i) + " uses texture " + std::to_string(t) + " which was never set");
     }
     RT_HIP(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
+    RT_HIP(c, wait_external(c, s));
 
     const DevScene &S = c->scene;
     const bool events = p->collect_events != 0;
@@ -391,7 +404,7 @@ int32_t rt_render(rt_ctx *c, uint32_t frame_index, int32_t accumulate, int32_t r
     rt_render_params p;
     std::memset(&p, 0, sizeof(p));
     p.frame_index = frame_index; p.accumulate = accumulate; p.seed = seed;
-    int32_t r = rt_render_device(c, &p, nullptr, nullptr, nullptr);
+    int32_t r = rt_render_device(c, &p, nullptr, nullptr, c->stream);
     if (r != RT_OK) return r;
     RT_HIP(c, hipEventRecord(c->evc0, c->stream));
     RT_HIP(c, hipMemcpyAsync(out, c->rgba.ptr, need, hipMemcpyDeviceToHost, c->stream));
@@ -407,6 +420,7 @@ int32_t rt_read_accum(rt_ctx *c, float *out, size_t n_vec4) {
     if (!c->has_camera) return fail(c, RT_ERR_STATE, "camera not set");
     if (!out || n_vec4 != (size_t)c->camera.width * c->camera.height) return fail(c, RT_ERR_INVALID_ARGUMENT, "out must hold width*height float4");
     RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, wait_external(c, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, hipMemcpy(out, c->accum.ptr, n_vec4 * 4 * sizeof(float), hipMemcpyDeviceToHost));
     return RT_OK;
@@ -435,6 +449,7 @@ int32_t rt_get_stats(rt_ctx *c, rt_stats *out) {
     return RT_OK;
 }
 
+void *rt_context_stream(rt_ctx *c) { return c ? (void *)c->stream : nullptr; }
 void *rt_device_rgba8(rt_ctx *c) { return c ? (void *)c->rgba.ptr : nullptr; }
 void *rt_device_accum(rt_ctx *c) { return c ? (void *)c->accum.ptr : nullptr; }
 
