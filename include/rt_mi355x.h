@@ -187,6 +187,7 @@ typedef enum rt_counter {
     RT_CNT_OCCLUSION_TAP,
     RT_CNT_MARCH_SHADE,     /* ray-marching hits shaded (fade + occlusion scale)       */
     RT_CNT_PIXEL_PACK,      /* clamp / accumulate / to_rgba                            */
+    RT_CNT_BVH_NODE,        /* box tests of the bounding-volume hierarchy (large scenes only; not in the reference) */
     RT_CNT_COUNT
 } rt_counter;
 
@@ -218,7 +219,8 @@ void rt_destroy(rt_ctx *ctx);
 
 /* Uploads Scene (src/scene.rs:13-25) as flat device arrays.  Validates what the reference
  * would panic on (material / texture / object indices out of range, src/ray_tracing/ray_tracing.rs:92,98)
- * and the limits of this backend: max_ray_bounces <= 32; Union/Substraction nesting depth <= 2. */
+ * and the limits of this backend: max_ray_bounces <= 32; Union/Substraction nesting depth <= 2.
+ * Scenes with 32 or more bounded objects are traced through a bounding-volume hierarchy (same hits as the linear scan). */
 int32_t rt_set_scene(rt_ctx *ctx, const rt_scene_desc *scene);
 
 /* Uploads Scene.textures[index]: tightly packed RGB8, row-major, exactly Texture.bytes

@@ -37,7 +37,7 @@ COUNTER_NAMES = [
     "hit_sphere", "hit_triangle", "hit_cuboid", "hit_plane", "hit_cylinder", "hit_cone",
     "light_call", "light_shade", "reflection_ray", "diffuse_ray", "refraction", "combine_refl", "combine_refr",
     "tex_fetch", "triplanar", "sdf_sphere", "sdf_cuboid", "sdf_cylinder", "sdf_plane", "sdf_union", "sdf_substraction",
-    "march_step", "sdfs_call", "occlusion_tap", "march_shade", "pixel_pack",
+    "march_step", "sdfs_call", "occlusion_tap", "march_shade", "pixel_pack", "bvh_node",
 ]
 RT_CNT_COUNT = len(COUNTER_NAMES)
 
@@ -57,6 +57,7 @@ EVENT_FLOPS = {
     "tex_fetch": 14, "triplanar": 62,
     "sdf_sphere": 47, "sdf_cuboid": 61, "sdf_cylinder": 57, "sdf_plane": 14, "sdf_union": 22, "sdf_substraction": 2,
     "march_step": 3, "occlusion_tap": 6, "march_shade": 9, "pixel_pack": 15,
+    "bvh_node": 21,  # slab test of one hierarchy node: executed work of the large-scene path, not reference arithmetic
 }
 
 

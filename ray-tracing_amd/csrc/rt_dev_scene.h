@@ -52,13 +52,14 @@ struct DevTexture {
     uint32_t width, height;
 };
 
-// Bounding-volume hierarchy over the sphere objects of a large scene (not part of the reference,
-// which scans all objects linearly; results are identical, see the traversal's tie rule).
+// Bounding-volume hierarchy for scenes with many objects (not part of the reference, which scans all objects
+// linearly; it only selects which objects get the reference's candidate test).  Nodes are stored in depth-first
+// order; `skip` is the node to continue with when the ray misses the box, so traversal needs no stack.
 struct DevBvhNode {
     float lo[3];
-    int32_t left;   // inner: index of the left child; leaf: first index into the primitive list
+    int32_t skip;  // index of the first node after this subtree
     float hi[3];
-    int32_t count;  // 0: inner node (right child = left + 1); > 0: leaf with `count` primitives
+    int32_t leaf;  // -1: inner node (first child = this + 1); else (first_prim << 4) | prim_count
 };
 
 struct DevScene {
@@ -69,6 +70,8 @@ struct DevScene {
     const DevTexture *textures;
     const DevBvhNode *bvh_nodes;   // null: linear scan
     const uint32_t *bvh_prims;     // object indices, leaf order
+    const uint32_t *unbounded;     // objects outside the hierarchy (planes), tested linearly
+    uint32_t n_bvh_nodes, n_unbounded;
     uint32_t n_objects, n_materials, n_lights, n_sdfs;
     float ambient[3];
     uint32_t max_ray_bounces;

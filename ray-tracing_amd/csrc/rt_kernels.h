@@ -224,6 +224,74 @@ RT_DEV int trace_closest(const DevScene &S, f3 ro, f3 rd, float &t_out, int &sub
     return best;
 }
 
+// One candidate test with a per-lane object (the object index differs between lanes: vector loads, divergent switch).
+template <bool EVENTS>
+RT_DEV bool cand_any(const DevObject &o, f3 ro, f3 rd, float &t, int &sub, Cnt<EVENTS> &cnt) {
+    sub = 0;
+    switch (o.kind) {
+        case RT_SPHERE: cnt.add(RT_CNT_TEST_SPHERE); return cand_sphere(o, ro, rd, t);
+        case RT_TRIANGLE: cnt.add(RT_CNT_TEST_TRIANGLE); return cand_triangle(o, ro, rd, t);
+        case RT_CUBOID: cnt.add(RT_CNT_TEST_CUBOID); return cand_cuboid(o, ro, rd, t);
+        case RT_PLANE: cnt.add(RT_CNT_TEST_PLANE); return cand_plane(o, ro, rd, t);
+        case RT_CYLINDER: cnt.add(RT_CNT_TEST_CYLINDER); return cand_cylinder(o, ro, rd, t, sub);
+        case RT_CONE: cnt.add(RT_CNT_TEST_CONE); return cand_cone(o, ro, rd, t, sub);
+        default: return false;
+    }
+}
+
+// trace_ray through the bounding-volume hierarchy.  Same candidate tests and the same acceptance rule as the linear
+// scan; because objects are visited in a different order, "first index wins ties" is applied explicitly.
+template <bool EVENTS>
+RT_DEV int trace_closest_bvh(const DevScene &S, f3 ro, f3 rd, float &t_out, int &sub_out, Cnt<EVENTS> &cnt, int ray_slot) {
+    cnt.ray(ray_slot);
+    float closest = RT_F32_MAX;
+    int best = -1, best_sub = 0;
+    for (uint32_t k = 0; k < S.n_unbounded; k++) {  // planes: wave-uniform loop
+        const uint32_t idx = S.unbounded[k];
+        const DevObject &o = S.objects[idx];
+        float t = 0.0f;
+        cnt.add(RT_CNT_TEST_PLANE);
+        if (cand_plane(o, ro, rd, t) && t > 0.0f && (t < closest || (t == closest && (int)idx < best))) { closest = t; best = (int)idx; best_sub = 0; }
+    }
+    const f3 inv = 1.0f / rd;
+    const int n_nodes = (int)S.n_bvh_nodes;
+    int i = 0;
+    while (i < n_nodes) {
+        const float4 a = reinterpret_cast<const float4 *>(S.bvh_nodes)[2 * i];
+        const float4 b = reinterpret_cast<const float4 *>(S.bvh_nodes)[2 * i + 1];
+        cnt.add(RT_CNT_BVH_NODE);
+        // slab test; fminf/fmaxf drop the NaNs of 0 * inf so such slabs do not cull
+        const float tx0 = (a.x - ro.x) * inv.x, tx1 = (b.x - ro.x) * inv.x;
+        const float ty0 = (a.y - ro.y) * inv.y, ty1 = (b.y - ro.y) * inv.y;
+        const float tz0 = (a.z - ro.z) * inv.z, tz1 = (b.z - ro.z) * inv.z;
+        const float tmin = rt_max(rt_max(rt_min(tx0, tx1), rt_min(ty0, ty1)), rt_max(rt_min(tz0, tz1), 0.0f));
+        const float tmax = rt_min(rt_min(rt_max(tx0, tx1), rt_max(ty0, ty1)), rt_max(tz0, tz1));
+        const bool hit = tmin <= tmax && tmin <= closest;
+        const int leaf = __float_as_int(b.w);
+        if (hit && leaf >= 0) {
+            const int first = leaf >> 4, count = leaf & 15;
+            for (int k = 0; k < count; k++) {
+                const int idx = (int)S.bvh_prims[first + k];
+                float t = 0.0f;
+                int sub = 0;
+                if (cand_any<EVENTS>(S.objects[idx], ro, rd, t, sub, cnt) && t > 0.0f && (t < closest || (t == closest && idx < best))) {
+                    closest = t; best = idx; best_sub = sub;
+                }
+            }
+        }
+        i = hit ? i + 1 : __float_as_int(a.w);
+    }
+    t_out = closest;
+    sub_out = best_sub;
+    return best;
+}
+
+template <bool EVENTS, bool BVH>
+RT_DEV int trace_ray(const DevScene &S, f3 ro, f3 rd, float &t_out, int &sub_out, Cnt<EVENTS> &cnt, int ray_slot) {
+    if (BVH) return trace_closest_bvh<EVENTS>(S, ro, rd, t_out, sub_out, cnt, ray_slot);
+    return trace_closest<EVENTS>(S, ro, rd, t_out, sub_out, cnt, ray_slot);
+}
+
 // ------------------------------------------------------------------------------------------------
 // finalise phase: RayHit of the closest candidate, same arithmetic as the reference's intersect()
 // ------------------------------------------------------------------------------------------------
@@ -307,27 +375,37 @@ RT_DEV void fin_triangle(const DevObject &o, f3 ro, f3 rd, float t, HitRec &h) {
     h.normal = normalize(sign * n);
 }
 
-// Completes the closest hit of every lane.  Lanes of a wave usually share a handful of winners, so the
-// loop visits each distinct winner once with a wave-uniform object (scalar loads, no divergent switch).
 template <bool EVENTS>
+RT_DEV void finalize_one(const DevObject &o, const DevMaterial &dm, f3 ro, f3 rd, float t, int sub, HitRec &h, Mtl &m, Cnt<EVENTS> &cnt) {
+    m = load_mtl(dm);
+    const bool need_uv = dm.texture >= 0 && dm.kind == RT_REFLECTIVE;
+    switch (o.kind) {
+        case RT_SPHERE: cnt.add(RT_CNT_HIT_SPHERE); fin_sphere(o, ro, rd, t, need_uv, h); break;
+        case RT_TRIANGLE: cnt.add(RT_CNT_HIT_TRIANGLE); fin_triangle(o, ro, rd, t, h); break;
+        case RT_CUBOID: cnt.add(RT_CNT_HIT_CUBOID); fin_cuboid(o, ro, rd, t, h); break;
+        case RT_PLANE: cnt.add(RT_CNT_HIT_PLANE); fin_plane(o, ro, rd, t, h); break;
+        case RT_CYLINDER: cnt.add(RT_CNT_HIT_CYLINDER); fin_cylinder(o, ro, rd, t, sub, need_uv, h); break;
+        default: cnt.add(RT_CNT_HIT_CONE); fin_cone(o, ro, rd, t, sub, need_uv, h); break;
+    }
+}
+
+// Completes the closest hit of every lane.  Small scenes: lanes of a wave usually share a handful of winners, so the
+// loop visits each distinct winner once with a wave-uniform object (scalar loads, no divergent switch).  Large scenes
+// (BVH): winners are mostly distinct, so every lane loads its own object.
+template <bool EVENTS, bool BVH>
 RT_DEV void finalize_hit(const DevScene &S, f3 ro, f3 rd, float t, int obj, int sub, HitRec &h, Mtl &m, Cnt<EVENTS> &cnt) {
     h.u = 0.0f; h.v = 0.0f;
+    if (BVH) {
+        const DevObject &o = S.objects[obj];
+        finalize_one<EVENTS>(o, S.materials[o.material], ro, rd, t, sub, h, m, cnt);
+        return;
+    }
     int pending = obj;
     while (true) {
         int cur = __builtin_amdgcn_readfirstlane(pending);
         if (pending == cur) {
             const DevObject &o = S.objects[cur];
-            const DevMaterial &dm = S.materials[o.material];
-            m = load_mtl(dm);
-            const bool need_uv = dm.texture >= 0 && dm.kind == RT_REFLECTIVE;
-            switch (o.kind) {
-                case RT_SPHERE: cnt.add(RT_CNT_HIT_SPHERE); fin_sphere(o, ro, rd, t, need_uv, h); break;
-                case RT_TRIANGLE: cnt.add(RT_CNT_HIT_TRIANGLE); fin_triangle(o, ro, rd, t, h); break;
-                case RT_CUBOID: cnt.add(RT_CNT_HIT_CUBOID); fin_cuboid(o, ro, rd, t, h); break;
-                case RT_PLANE: cnt.add(RT_CNT_HIT_PLANE); fin_plane(o, ro, rd, t, h); break;
-                case RT_CYLINDER: cnt.add(RT_CNT_HIT_CYLINDER); fin_cylinder(o, ro, rd, t, sub, need_uv, h); break;
-                default: cnt.add(RT_CNT_HIT_CONE); fin_cone(o, ro, rd, t, sub, need_uv, h); break;
-            }
+            finalize_one<EVENTS>(o, S.materials[o.material], ro, rd, t, sub, h, m, cnt);
             break;
         }
     }
@@ -354,7 +432,7 @@ RT_DEV void light_dir_dist(const DevLight &l, f3 point, f3 &dir, float &dist) {
 }
 
 // RayTracing::light (src/ray_tracing/ray_tracing.rs:28-57)
-template <bool EVENTS>
+template <bool EVENTS, bool BVH>
 RT_DEV f3 shade_lights(const DevScene &S, f3 ray_dir, const HitRec &h, f3 albedo, const Mtl &m, int obj_index, Cnt<EVENTS> &cnt) {
     cnt.add(RT_CNT_LIGHT_CALL);
     f3 l_acc = splat3(0.0f);
@@ -374,7 +452,7 @@ RT_DEV f3 shade_lights(const DevScene &S, f3 ray_dir, const HitRec &h, f3 albedo
             f3 ldir; float ldist;
             light_dir_dist(l, h.point, ldir, ldist);
             float st; int ssub;
-            int idx = trace_closest<EVENTS>(S, so, -ldir, st, ssub, cnt, RT_CNT_RAYS_SHADOW);
+            int idx = trace_ray<EVENTS, BVH>(S, so, -ldir, st, ssub, cnt, RT_CNT_RAYS_SHADOW);
             if (idx >= 0 && idx != obj_index) l_acc = l_acc * 0.5f;
         }
     }
@@ -499,9 +577,10 @@ enum { FK_REFL = 0, FK_REFR1 = 1, FK_REFR2 = 2, FK_PASS = 3 };
 // ray tracing kernel
 //   REFR   : the scene has refractive materials (two-child frames are compiled in)
 //   RDEPTH : capacity of the per-lane refractive frame array (>= max_ray_bounces when REFR)
+//   BVH    : closest hits go through the bounding-volume hierarchy (scenes with many objects)
 //   dynamic LDS: max_ray_bounces * 4 * blockDim.x floats (reflective frames, one column per lane)
 // ------------------------------------------------------------------------------------------------
-template <bool EVENTS, bool REFR, int RDEPTH>
+template <bool EVENTS, bool REFR, int RDEPTH, bool BVH>
 __global__ void __launch_bounds__(256) rt_trace_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
     extern __shared__ float s_frames[];
     __shared__ uint32_t s_cnt[(EVENTS ? RT_CNT_COUNT : 0) + 1];
@@ -539,18 +618,18 @@ __global__ void __launch_bounds__(256) rt_trace_kernel(const DevScene S, const D
                 have_value = true;
             } else {
                 float t; int sub;
-                int obj = trace_closest<EVENTS>(S, ro, rd, t, sub, cnt, ray_slot);
+                int obj = trace_ray<EVENTS, BVH>(S, ro, rd, t, sub, cnt, ray_slot);
                 if (obj < 0) {
                     V = L + ambient * Cc;
                     have_value = true;
                 } else {
                     HitRec h; Mtl m;
-                    finalize_hit<EVENTS>(S, ro, rd, t, obj, sub, h, m, cnt);
+                    finalize_hit<EVENTS, BVH>(S, ro, rd, t, obj, sub, h, m, cnt);
                     f3 albedo = m.albedo;
                     if (m.kind == RT_REFLECTIVE) {
                         if (m.texture >= 0) { cnt.add(RT_CNT_TEX_FETCH); albedo = tex_from_uv(S.textures[m.texture], h.u, h.v); }
                         f3 p;
-                        if (!dmode) p = shade_lights<EVENTS>(S, rd, h, albedo, m, obj, cnt);
+                        if (!dmode) p = shade_lights<EVENTS, BVH>(S, rd, h, albedo, m, obj, cnt);
                         else p = L + m.emission_power * albedo;
                         cnt.add(scene_diffuse ? RT_CNT_DIFFUSE_RAY : RT_CNT_REFLECTION_RAY);
                         f3 no, nd;
@@ -576,7 +655,7 @@ __global__ void __launch_bounds__(256) rt_trace_kernel(const DevScene S, const D
                         f3 lo = h.point + RT_EPSILON * h.normal;
                         f3 ldv = rt_reflect(rd, h.normal);
                         f3 p;
-                        if (!dmode) p = shade_lights<EVENTS>(S, rd, h, albedo, m, obj, cnt);
+                        if (!dmode) p = shade_lights<EVENTS, BVH>(S, rd, h, albedo, m, obj, cnt);
                         else p = L + m.emission_power * albedo;
                         f3 cchild = Cc * albedo;
                         float *f = rfr[depth];

@@ -53,6 +53,7 @@ struct rt_ctx {
     DevBuf<DevTexture> textures;
     DevBuf<DevBvhNode> bvh_nodes;
     DevBuf<uint32_t> bvh_prims;
+    DevBuf<uint32_t> unbounded;
     DevBuf<uint32_t> tex_data[kMaxTextures];
     DevTexture h_textures[kMaxTextures] = {};
     std::vector<int32_t> mat_texture;  // texture index of every material, for the render-time check
@@ -148,7 +149,7 @@ void rt_destroy(rt_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->objects.release(); c->materials.release(); c->lights.release(); c->sdfs.release(); c->textures.release();
-    c->bvh_nodes.release(); c->bvh_prims.release();
+    c->bvh_nodes.release(); c->bvh_prims.release(); c->unbounded.release();
     for (auto &t : c->tex_data) t.release();
     c->rgba.release(); c->accum.release(); c->counters.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -266,15 +267,18 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.diffuse = d->diffuse; S.enable_accumulation = d->enable_accumulation;
 
     // Large all-sphere scenes get a bounding-volume hierarchy; small or mixed scenes keep the reference's linear scan.
-    S.bvh_nodes = nullptr; S.bvh_prims = nullptr;
+    S.bvh_nodes = nullptr; S.bvh_prims = nullptr; S.unbounded = nullptr; S.n_bvh_nodes = 0; S.n_unbounded = 0;
     if (!d->ray_marching && rt_bvh_wanted(d)) {
-        std::vector<DevBvhNode> nodes; std::vector<uint32_t> prims;
-        rt_bvh_build(d, nodes, prims);
+        std::vector<DevBvhNode> nodes; std::vector<uint32_t> prims, unbounded;
+        rt_bvh_build(d, nodes, prims, unbounded);
         RT_HIP(c, c->bvh_nodes.ensure(nodes.size()));
         RT_HIP(c, c->bvh_prims.ensure(prims.size()));
+        RT_HIP(c, c->unbounded.ensure(unbounded.size() ? unbounded.size() : 1));
         RT_HIP(c, hipMemcpy(c->bvh_nodes.ptr, nodes.data(), nodes.size() * sizeof(DevBvhNode), hipMemcpyHostToDevice));
         RT_HIP(c, hipMemcpy(c->bvh_prims.ptr, prims.data(), prims.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        S.bvh_nodes = c->bvh_nodes.ptr; S.bvh_prims = c->bvh_prims.ptr;
+        if (!unbounded.empty()) RT_HIP(c, hipMemcpy(c->unbounded.ptr, unbounded.data(), unbounded.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        S.bvh_nodes = c->bvh_nodes.ptr; S.bvh_prims = c->bvh_prims.ptr; S.unbounded = c->unbounded.ptr;
+        S.n_bvh_nodes = (uint32_t)nodes.size(); S.n_unbounded = (uint32_t)unbounded.size();
     }
     c->has_scene = true;
     return RT_OK;
@@ -376,16 +380,19 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
         else launch(rt_march_kernel<false>, blocks, threads, 0, s, S, c->camera, F);
     } else {
         const size_t lds = (size_t)(maxd ? maxd : 1u) * 4u * threads * sizeof(float);
-        const bool refr = c->has_refractive;
-        if (!refr) {
-            if (events) launch(rt_trace_kernel<true, false, 1>, blocks, threads, lds, s, S, c->camera, F);
-            else launch(rt_trace_kernel<false, false, 1>, blocks, threads, lds, s, S, c->camera, F);
-        } else if (maxd <= 8u) {
-            if (events) launch(rt_trace_kernel<true, true, 8>, blocks, threads, lds, s, S, c->camera, F);
-            else launch(rt_trace_kernel<false, true, 8>, blocks, threads, lds, s, S, c->camera, F);
-        } else {
-            if (events) launch(rt_trace_kernel<true, true, 32>, blocks, threads, lds, s, S, c->camera, F);
-            else launch(rt_trace_kernel<false, true, 32>, blocks, threads, lds, s, S, c->camera, F);
+        // kernel variant: bit 0 events, bits 1-2 refractive frames (0 none, 1 up to 8, 2 up to 32), bit 3 hierarchy
+        const int rsel = !c->has_refractive ? 0 : (maxd <= 8u ? 1 : 2);
+        const int variant = (events ? 1 : 0) | (rsel << 1) | (S.bvh_nodes ? 8 : 0);
+        switch (variant) {
+#define RT_CASE(V, E, R, D, B) case V: launch(rt_trace_kernel<E, R, D, B>, blocks, threads, lds, s, S, c->camera, F); break;
+            RT_CASE(0, false, false, 1, false) RT_CASE(1, true, false, 1, false)
+            RT_CASE(2, false, true, 8, false) RT_CASE(3, true, true, 8, false)
+            RT_CASE(4, false, true, 32, false) RT_CASE(5, true, true, 32, false)
+            RT_CASE(8, false, false, 1, true) RT_CASE(9, true, false, 1, true)
+            RT_CASE(10, false, true, 8, true) RT_CASE(11, true, true, 8, true)
+            RT_CASE(12, false, true, 32, true) RT_CASE(13, true, true, 32, true)
+#undef RT_CASE
+            default: return fail(c, RT_ERR_STATE, "no kernel variant");
         }
     }
     RT_HIP(c, hipGetLastError());

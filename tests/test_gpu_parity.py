@@ -39,7 +39,7 @@ def test_deterministic_scenes_match_oracle(pkg, orc, ctx, name, size):
     ref = orc.render(s.desc, s.camera(*size), s.textures(), want_counters=True, n_threads=8)
     assert_parity(rgba, ref["rgba"], lin, ref["accum"], what=f"{name} {size}")
     cref = dict(zip(pkg.COUNTER_NAMES, ref["counters"]))
-    assert {k: st[k] for k in pkg.COUNTER_NAMES} == cref, "event counters differ from the oracle's"
+    assert {k: st[k] for k in pkg.COUNTER_NAMES} == cref, "event counters differ"
     assert st["rays_total"] == sum(cref[k] for k in pkg.COUNTER_NAMES[:5])
 
 
@@ -293,3 +293,70 @@ def test_full_size_4k_properties(pkg, orc, ctx, name):
     for row in (0, 537, 1080, 1611, 2159):
         ref = orc.render(s.desc, cam, s.textures(), rows=(row, row + 1))
         assert_parity(rgba[row:row + 1], ref["rgba"][row:row + 1], a[row:row + 1], ref["accum"][row:row + 1], what=f"{name} 4K row {row}")
+
+
+def _counters_without_candidate_tests(pkg, d):
+    skip = {"test_sphere", "test_triangle", "test_cuboid", "test_plane", "test_cylinder", "test_cone", "bvh_node"}
+    return {k: d[k] for k in pkg.COUNTER_NAMES if k not in skip}
+
+
+@pytest.mark.parametrize("name", ["spheres200", "spheres1k"])
+def test_hierarchy_traversal_equals_linear_scan_on_sphere_fields(pkg, orc, ctx, name):
+    """Scenes with >= 32 bounded objects go through the bounding-volume hierarchy; the oracle scans linearly."""
+    s = pkg.Scene(name)
+    w, h = 160, 120
+    ctx.load(s, w, h)
+    ctx.reset_accum()
+    acc = np.zeros((h, w, 4), dtype=np.float32)
+    for f in (1, 2):
+        rgba = ctx.render(frame_index=f, accumulate=True, reset_accum=False, seed=9)
+        ref = orc.render(s.desc, s.camera(w, h), (), frame_index=f, accumulate=True, seed=9, accum=acc, n_threads=8, want_counters=True)
+        assert_parity(rgba, ref["rgba"], ctx.read_accum(), acc, what=f"{name} frame {f}")
+    ctx.reset_accum()
+    ctx.render_device(frame_index=2, accumulate=True, seed=9, collect_events=True)
+    st = ctx.stats()
+    cref = dict(zip(pkg.COUNTER_NAMES, ref["counters"]))
+    assert _counters_without_candidate_tests(pkg, st) == _counters_without_candidate_tests(pkg, cref)
+    assert 0 < st["test_sphere"] < cref["test_sphere"] / 4 and st["bvh_node"] > 0, "the hierarchy must cull most candidates"
+
+
+def test_hierarchy_with_every_primitive_kind_shadows_textures_and_glass(pkg, orc, ctx):
+    """A random field of all six primitive kinds (two planes outside the hierarchy), Whitted mode with shadows."""
+    rng = np.random.default_rng(42)
+    mats = [make_material(pkg, albedo=tuple(rng.uniform(0.2, 0.9, 3)), roughness=float(rng.uniform(0.3, 1.0)), ambience=0.4,
+                          shininess=float(rng.uniform(5, 80)), specular=float(rng.uniform(0.2, 1.5))) for _ in range(6)]
+    mats.append(make_material(pkg, albedo=(0.9, 0.95, 1.0), kind=pkg.RT_REFRACTIVE, transparency=0.9, refraction_index=1.3, reflectivity=0.1))
+    mats.append(make_material(pkg, albedo=(0.5, 0.5, 0.5), texture=0, roughness=0.8, ambience=0.4))
+    mats.append(make_material(pkg, albedo=(0.5, 0.5, 0.5), texture=3, roughness=0.6, ambience=0.3))
+    objs = [make_object(pkg, pkg.RT_PLANE, 7, normal=(0, 1, 0), point=(0, -0.5, 0), max_dist=(12, 12), has_max_dist=1),
+            make_object(pkg, pkg.RT_PLANE, 1, normal=(0, 0, 1), point=(0, 0, -9))]
+    for i in range(60):
+        pos = (float(rng.uniform(-6, 6)), float(rng.uniform(-0.2, 2.5)), float(rng.uniform(-7, 2)))
+        rot = tuple(float(a) for a in rng.uniform(-180, 180, 3))
+        m = int(rng.integers(0, 9))
+        kind = i % 5
+        if kind == 0:
+            objs.append(make_object(pkg, pkg.RT_SPHERE, m, position=pos, rotation_axis=rot, radius=float(rng.uniform(0.2, 0.7))))
+        elif kind == 1:
+            objs.append(make_object(pkg, pkg.RT_CUBOID, m, position=pos, rotation_axis=rot, dimension=tuple(float(a) for a in rng.uniform(0.15, 0.6, 3))))
+        elif kind == 2:
+            objs.append(make_object(pkg, pkg.RT_CYLINDER, m, position=pos, rotation_axis=rot, radius=0.3, height=1.0))
+        elif kind == 3:
+            objs.append(make_object(pkg, pkg.RT_CONE, m, position=pos, rotation_axis=rot, radius=float(rng.uniform(0.2, 0.6)), height=float(rng.uniform(0.4, 1.2))))
+        else:
+            v1 = np.array(pos)
+            objs.append(make_object(pkg, pkg.RT_TRIANGLE, m, v1=tuple(v1), v2=tuple(v1 + rng.uniform(-1, 1, 3)), v3=tuple(v1 + rng.uniform(-1, 1, 3))))
+    lights = [make_light(pkg, pkg.RT_POSITIONAL, (1, 1, 1), (3, 5, 4), 30.0), make_light(pkg, pkg.RT_DIRECTIONAL, (1, 0.9, 0.8), (0.3, -1, -0.2), 0.8)]
+    sb = SceneBuilder(pkg, objs, mats, lights, n_textures=4, max_ray_bounces=5, shadow_casting=1, ambient_color=(0.05, 0.08, 0.12))
+    cam = pkg.make_camera((0.5, 2.5, 9.0), (-0.05, -0.2, -1.0), 240, 160)
+    tex = pkg.load_textures()
+    for i, t in enumerate(tex):
+        ctx.set_texture(i, t)
+    ctx.set_scene(sb.desc)
+    ctx.set_camera(cam)
+    rgba, lin, st = gpu_frame(ctx, events=True)
+    ref = orc.render(sb.desc, cam, tex, want_counters=True, n_threads=8)
+    assert_parity(rgba, ref["rgba"], lin, ref["accum"], what="mixed field")
+    cref = dict(zip(pkg.COUNTER_NAMES, ref["counters"]))
+    assert _counters_without_candidate_tests(pkg, st) == _counters_without_candidate_tests(pkg, cref)
+    assert st["bvh_node"] > 0 and all(cref[k] > 0 for k in ("hit_sphere", "hit_cuboid", "hit_cylinder", "hit_cone", "hit_triangle", "hit_plane", "refraction", "tex_fetch"))
