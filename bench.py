@@ -32,13 +32,13 @@ import __graft_entry__ as graft  # noqa: E402
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X: 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz (packed FP32 FMA)
 
 WORKLOADS = {
-    # name: (scene, width, height, max_ray_bounces or None, accumulate, description)
-    "scene3_4k": ("scene3", 3840, 2160, 5, False, "reference default scene (plane + sphere, 2 lights, shadows), 3840x2160, 1 spp, max 5 bounces"),
-    "scene1_4k": ("scene1", 3840, 2160, 5, False, "all-primitives textured scene, 3840x2160, 1 spp, max 5 bounces"),
-    "tex4_4k": ("tex4", 3840, 2160, 5, False, "four textured spheres over a chess plane, 3840x2160, 1 spp, max 5 bounces"),
-    "scene4_4k": ("scene4", 3840, 2160, None, False, "ray-marching SDF scene, 3840x2160, 255 max march steps"),
-    "scene2_4k": ("scene2", 3840, 2160, 5, True, "diffuse emissive path tracing with accumulation, 3840x2160"),
-    "spheres10k_8k": ("spheres10k", 7680, 4320, 5, True, "10 000 diffuse spheres, 7680x4320, accumulated samples"),
+    # name: (scene, width, height, max_ray_bounces or None, accumulate, samples per step, default sharding, description)
+    "scene3_4k": ("scene3", 3840, 2160, 5, False, 1, "frames", "reference default scene (plane + sphere, 2 lights, shadows), 3840x2160, 1 spp, max 5 bounces"),
+    "scene1_4k": ("scene1", 3840, 2160, 5, False, 1, "frames", "all-primitives textured scene, 3840x2160, 1 spp, max 5 bounces"),
+    "tex4_4k": ("tex4", 3840, 2160, 5, False, 1, "frames", "four textured spheres over a chess plane, 3840x2160, 1 spp, max 5 bounces"),
+    "scene4_4k": ("scene4", 3840, 2160, None, False, 1, "frames", "ray-marching SDF scene, 3840x2160, 255 max march steps"),
+    "scene2_4k": ("scene2", 3840, 2160, 5, True, 1, "frames", "diffuse emissive path tracing with accumulation, 3840x2160"),
+    "spheres10k_8k": ("spheres10k", 7680, 4320, 5, True, 64, "samples", "10 000 diffuse spheres, 7680x4320, 64 spp accumulated per frame"),
 }
 
 
@@ -48,7 +48,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="scene3_4k", choices=sorted(WORKLOADS))
-    ap.add_argument("--shard", default="frames", choices=["frames", "rows", "samples"])
+    ap.add_argument("--shard", default=None, choices=["frames", "rows", "samples"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -65,7 +65,8 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
 
     pkg = graft.load_package()
-    scene_name, width, height, bounces, accumulate, description = WORKLOADS[args.workload]
+    scene_name, width, height, bounces, accumulate, spp, default_shard, description = WORKLOADS[args.workload]
+    shard = args.shard or default_shard
     scene = pkg.Scene(scene_name)
     if bounces is not None:
         scene.desc.max_ray_bounces = bounces
@@ -75,20 +76,49 @@ def main() -> None:
     rgba = torch.zeros((height, width, 4), dtype=torch.uint8, device="cuda")
     accum = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
-    rows = pkg.shard_rows(height, rank, world) if (args.shard == "rows" and world > 1) else None
+    sh = stream.cuda_stream
+    my_rows = pkg.shard_rows(height, rank, world)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def render(sample_index: int, rows=None, acc: bool = accumulate) -> None:
+        ctx.render_device(frame_index=sample_index if acc else 1, accumulate=acc, seed=0x5EED, rows=rows,
+                          d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh)
+
     def step(i: int) -> None:
-        # frames sharded over ranks: rank r renders frames r, r + world, ... of the sequence (sample index when accumulating)
-        frame = 1 + i * world + rank if args.shard != "rows" else 1 + i
-        ctx.render_device(frame_index=frame if accumulate else 1, accumulate=accumulate, seed=0x5EED + frame, rows=rows,
-                          d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=stream.cuda_stream)
-        if args.shard == "samples" and world > 1:
-            dist.all_reduce(accum)
+        if shard == "frames":
+            # whole frames of a sequence go to different ranks: rank r renders frames r, r + world, ...; no collective
+            for k in range(spp):
+                render(1 + (i * world + rank) * spp + k)
+        elif shard == "rows":
+            # one frame per step, one row band per rank; the bands are all-gathered so that every rank holds the frame
+            for k in range(spp):
+                render(1 + i * spp + k, rows=my_rows if world > 1 else None)
+            if world > 1:
+                rgba.copy_(pkg.gather_row_bands(dist, rgba, height, rank, world))
+        else:
+            # the spp samples of one accumulated frame are split by sample index; one all-reduce of the accumulators,
+            # then every rank resolves (divide, clamp, pack) the rows it owns
+            accum.zero_()
+            pkg.render_sample_sharded(dist if world > 1 else None, lambda idx: render(idx, acc=True), accum, spp, rank, world, first_index=1 + i * spp)
+            ctx.resolve_device(spp, rows=my_rows, d_accum=accum.data_ptr(), d_rgba8=rgba.data_ptr(), stream=sh)
+
+    def rays_of_step(i: int) -> int:
+        """Rays this rank traces in step i (untimed pass: one stats read-back per render)."""
+        total = 0
+        if shard == "samples":
+            ids = pkg.shard_samples(spp, rank, world, 1 + i * spp)
+        elif shard == "frames":
+            ids = [1 + (i * world + rank) * spp + k for k in range(spp)]
+        else:
+            ids = [1 + i * spp + k for k in range(spp)]
+        for idx in ids:
+            render(idx, rows=my_rows if (shard == "rows" and world > 1) else None, acc=accumulate or shard == "samples")
+            total += ctx.stats()["rays_total"]
+        return total
 
     for i in range(args.warmup):
         step(i)
@@ -101,8 +131,13 @@ def main() -> None:
     ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration on the launch stream (back-to-back launches)
-    rays_rank = ctx.stats()["rays_total"]            # rays of the last frame; deterministic scenes trace the same number every frame
+    launches_per_step = len(pkg.shard_samples(spp, rank, world)) if shard == "samples" else spp
+    # average launch duration of the dominant kernel on the launch stream (launches are back to back; at 1 spp without
+    # collectives this is the whole step)
+    kernel_ms = ev0.elapsed_time(ev1) / (args.steps * launches_per_step)
+    # rays per step: deterministic scenes trace the same rays every frame; random modes vary by < 0.1 % between sample sets,
+    # so the count of the first timed step's sample set stands for every step
+    rays_rank = rays_of_step(args.warmup)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     r = torch.tensor([float(rays_rank)], dtype=torch.float64, device="cuda")
@@ -114,8 +149,8 @@ def main() -> None:
 
     if rank == 0:
         # algorithmic FLOPs of one frame: event counts of a (slower, untimed) counting render times the per-event constants
-        ctx.render_device(frame_index=1, accumulate=False, seed=0x5EED + 1, rows=rows, collect_events=True,
-                          d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=stream.cuda_stream)
+        ctx.render_device(frame_index=1, accumulate=False, seed=0x5EED, rows=my_rows if (shard == "rows" and world > 1) else None,
+                          collect_events=True, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh)
         st = ctx.stats()
         flops = pkg.algorithmic_flops(st)
         achieved = flops / (kernel_ms * 1e-3) / 1e12
@@ -129,13 +164,14 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak" if args.shard == "frames" else "strong",
+            "scaling": "weak" if shard == "frames" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {description}", "width": width, "height": height,
-                       "max_ray_bounces": int(scene.desc.max_ray_bounces), "rays_per_frame": int(rays_rank),
-                       "parallelism": f"{args.shard}-sharded x{world}" if world > 1 else "single GPU"},
+                       "max_ray_bounces": int(scene.desc.max_ray_bounces), "samples_per_step": spp,
+                       "rays_per_step_per_rank": int(rays_rank), "sharding": shard,
+                       "parallelism": f"{shard}-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": None,
                          "kernel": "rt_march_kernel" if scene.desc.ray_marching else "rt_trace_kernel",

@@ -245,6 +245,12 @@ int32_t rt_render(rt_ctx *ctx, uint32_t frame_index, int32_t accumulate, int32_t
  * returns after the launch; the context's other calls wait for it before touching its buffers. */
 int32_t rt_render_device(rt_ctx *ctx, const rt_render_params *params, void *d_rgba8, void *d_accum, void *stream);
 
+/* render_chunk's accumulation tail (src/renderer.rs:62-66) on its own: out = to_rgba(clamp(accum / sample_count, 0, 1))
+ * for rows [row_begin, row_end) (0,0 = all).  Used when the samples of one frame were rendered by several GPUs and
+ * their accumulators summed (all-reduce) outside this library; d_accum/d_rgba8 NULL = the context's own buffers. */
+int32_t rt_resolve_device(rt_ctx *ctx, uint32_t sample_count, uint32_t row_begin, uint32_t row_end, void *d_accum,
+                          void *d_rgba8, void *stream);
+
 /* Zeroes the context's accumulator (Renderer::render on `updated`, src/renderer.rs:93-96). */
 int32_t rt_reset_accum(rt_ctx *ctx);
 

@@ -121,7 +121,7 @@ class rt_render_params(C.Structure):
 # every symbol include/rt_mi355x.h declares
 ABI_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_texture", "rt_set_camera", "rt_render", "rt_render_device",
-    "rt_reset_accum", "rt_read_accum", "rt_get_stats", "rt_context_stream", "rt_device_rgba8", "rt_device_accum", "rt_last_error",
+    "rt_resolve_device", "rt_reset_accum", "rt_read_accum", "rt_get_stats", "rt_context_stream", "rt_device_rgba8", "rt_device_accum", "rt_last_error",
     "rt_abi_version",
 ]
 
@@ -152,6 +152,7 @@ def lib() -> C.CDLL:
         l.rt_set_camera.argtypes = [vp, C.POINTER(rt_camera_desc)]; l.rt_set_camera.restype = C.c_int32
         l.rt_render.argtypes = [vp, C.c_uint32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_size_t]; l.rt_render.restype = C.c_int32
         l.rt_render_device.argtypes = [vp, C.POINTER(rt_render_params), vp, vp, vp]; l.rt_render_device.restype = C.c_int32
+        l.rt_resolve_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]; l.rt_resolve_device.restype = C.c_int32
         l.rt_reset_accum.argtypes = [vp]; l.rt_reset_accum.restype = C.c_int32
         l.rt_read_accum.argtypes = [vp, C.c_void_p, C.c_size_t]; l.rt_read_accum.restype = C.c_int32
         l.rt_get_stats.argtypes = [vp, C.POINTER(rt_stats)]; l.rt_get_stats.restype = C.c_int32
@@ -321,6 +322,14 @@ class Context:
         self._check(self._l.rt_render_device(self._ctx, C.byref(p), C.c_void_p(d_rgba8 or None), C.c_void_p(d_accum or None),
                                              C.c_void_p(stream or None)), "rt_render_device")
 
+    def resolve_device(self, sample_count: int, rows: Optional[tuple] = None, d_accum: int = 0, d_rgba8: int = 0, stream: Optional[int] = None):
+        """rt_resolve_device: accumulated / sample_count -> clamp -> RGBA8 (after an external all-reduce of accumulators)."""
+        rb, re = rows if rows is not None else (0, 0)
+        if stream is None:
+            stream = int(self._l.rt_context_stream(self._ctx) or 0)
+        self._check(self._l.rt_resolve_device(self._ctx, sample_count, rb, re, C.c_void_p(d_accum or None), C.c_void_p(d_rgba8 or None),
+                                              C.c_void_p(stream or None)), "rt_resolve_device")
+
     def reset_accum(self):
         self._check(self._l.rt_reset_accum(self._ctx), "rt_reset_accum")
 
@@ -357,13 +366,4 @@ class Context:
             pass
 
 
-def shard_rows(height: int, rank: int, world_size: int, band: int = 8) -> tuple:
-    """Row band [begin, end) of `rank` when a frame is split over `world_size` GPUs.
-
-    Bands are contiguous and aligned to the kernels' 8-row tiles; the last ranks may get one band less.
-    """
-    n_bands = (height + band - 1) // band
-    base, extra = divmod(n_bands, world_size)
-    first = rank * base + min(rank, extra)
-    count = base + (1 if rank < extra else 0)
-    return min(first * band, height), min((first + count) * band, height)
+from .sharding import gather_row_bands, render_sample_sharded, shard_rows, shard_samples  # noqa: E402,F401

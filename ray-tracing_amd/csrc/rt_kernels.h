@@ -951,3 +951,14 @@ __global__ void __launch_bounds__(256) rt_march_kernel(const DevScene S, const D
     }
     flush_counters<EVENTS>(F, cnt, s_cnt);
 }
+
+// ------------------------------------------------------------------------------------------------
+// resolve: accumulated / sample_count -> clamp -> to_rgba (src/renderer.rs:62-66, :29-36); HBM-bound, 20 B per pixel
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rt_resolve_kernel(const float4 *__restrict__ accum, uint32_t *__restrict__ rgba, uint32_t first, uint32_t count, float samples) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const float4 a = accum[first + i];
+        const float x = rt_clamp01_sse(a.x / samples), y = rt_clamp01_sse(a.y / samples), z = rt_clamp01_sse(a.z / samples), w = rt_clamp01_sse(a.w / samples);
+        rgba[first + i] = rt_as_u8(x * 255.0f) | (rt_as_u8(y * 255.0f) << 8) | (rt_as_u8(z * 255.0f) << 16) | (rt_as_u8(w + 255.0f) << 24);
+    }
+}

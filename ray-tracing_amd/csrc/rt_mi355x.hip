@@ -6,6 +6,7 @@
 // which the kernels fold into ray generation.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -399,6 +400,23 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
     RT_HIP(c, hipEventRecord(c->ev1, s));
     c->last_blocks = blocks; c->last_ncnt = ncnt; c->last_events = events; c->timed = true; c->last_stream = s;
     c->frames += 1;
+    return RT_OK;
+}
+
+int32_t rt_resolve_device(rt_ctx *c, uint32_t sample_count, uint32_t row_begin, uint32_t row_end, void *d_accum, void *d_rgba8, void *stream) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!c->has_camera) return fail(c, RT_ERR_STATE, "camera not set");
+    if (sample_count == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "sample_count must be >= 1");
+    if (row_begin == 0 && row_end == 0) row_end = c->camera.height;
+    if (row_end > c->camera.height || row_begin >= row_end) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad row range");
+    RT_HIP(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    RT_HIP(c, wait_external(c, s));
+    const uint32_t first = row_begin * c->camera.width, count = (row_end - row_begin) * c->camera.width;
+    const uint32_t blocks = std::min<uint32_t>((count + 255u) / 256u, 256u * 8u);
+    hipLaunchKernelGGL(rt_resolve_kernel, dim3(blocks), dim3(256), 0, s, (const float4 *)(d_accum ? d_accum : (void *)c->accum.ptr),
+                       (uint32_t *)(d_rgba8 ? d_rgba8 : (void *)c->rgba.ptr), first, count, (float)sample_count);
+    RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
 

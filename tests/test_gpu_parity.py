@@ -360,3 +360,28 @@ def test_hierarchy_with_every_primitive_kind_shadows_textures_and_glass(pkg, orc
     cref = dict(zip(pkg.COUNTER_NAMES, ref["counters"]))
     assert _counters_without_candidate_tests(pkg, st) == _counters_without_candidate_tests(pkg, cref)
     assert st["bvh_node"] > 0 and all(cref[k] > 0 for k in ("hit_sphere", "hit_cuboid", "hit_cylinder", "hit_cone", "hit_triangle", "hit_plane", "refraction", "tex_fetch"))
+
+
+def test_resolve_after_external_accumulation(pkg, orc, ctx):
+    """rt_resolve_device: the accumulate tail of render_chunk on an accumulator that was summed outside the library
+    (sample-index sharding over GPUs followed by an all-reduce)."""
+    import torch
+    s = pkg.Scene("scene2")
+    w, h = 128, 96
+    ctx.load(s, w, h)
+    parts = []
+    for shard in range(2):  # two "ranks", each with its own zeroed accumulator and interleaved sample indices
+        acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        for idx in pkg.shard_samples(6, shard, 2):
+            ctx.render_device(frame_index=idx, accumulate=True, seed=0x5EED, d_accum=acc.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        parts.append(acc)
+    torch.cuda.synchronize()
+    total = parts[0] + parts[1]
+    rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    ctx.resolve_device(6, d_accum=total.data_ptr(), d_rgba8=rgba.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref_acc = np.zeros((h, w, 4), dtype=np.float32)
+    for f in range(1, 7):
+        ref = orc.render(s.desc, s.camera(w, h), (), frame_index=f, accumulate=True, seed=0x5EED, accum=ref_acc)
+    # summation order differs from the sequential += of the reference: tolerance, not identity
+    assert_parity(rgba.cpu().numpy(), ref["rgba"], total.cpu().numpy() / 6.0, ref_acc / 6.0, exact=False, what="sample-sharded resolve")
