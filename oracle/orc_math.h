@@ -49,47 +49,47 @@ static inline uint32_t as_u32(float f) { if (!(f > 0.0f)) return 0; if (f >= 429
 #undef RT_POW_TABLE_QUAL
 #undef RT_POW_TABLE_NAME
 
-// log2 of a positive, finite, normal double; relative accuracy ~1e-15 (also next to 1).
-static inline double pow_log2(double ax) {
-    uint64_t b = d2u(ax);
-    int e = (int)(b >> 52) - 1023;
-    double z = u2d((b & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL);
-    if (z >= 1.46875) { z = z * 0.5; e += 1; }
-    int i = (int)(z * 16.0 - 11.5);
-    double r = z * orc_pow_invc[i] - 1.0;
-    double p = orc_pow_logpoly[7];
-    p = p * r + orc_pow_logpoly[6];
-    p = p * r + orc_pow_logpoly[5];
-    p = p * r + orc_pow_logpoly[4];
-    p = p * r + orc_pow_logpoly[3];
-    p = p * r + orc_pow_logpoly[2];
-    p = p * r + orc_pow_logpoly[1];
-    p = p * r + orc_pow_logpoly[0];
-    return ((double)e + orc_pow_logc[i]) + p * r;
-}
+// Fused multiply-add in binary64.  The result is defined by IEEE 754 (one rounding), so hardware FMA and the
+// libm fallback agree bit for bit; target_clones only picks the fast one where the CPU has it.
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define ORC_FMA_CLONES __attribute__((target_clones("fma", "default")))
+#else
+#define ORC_FMA_CLONES
+#endif
 
-// 2^E for |E| <= 200.
-static inline double pow_exp2(double E) {
-    const double SHIFT = 6755399441055744.0;  // 1.5 * 2^52: adding it rounds to an integer (RN)
+// powf(ax, y) for ax > 0 finite: exp2(y * log2(ax)) in binary64 (algorithm: tools/gen_pow_tables.py).
+ORC_FMA_CLONES __attribute__((noinline)) static float pow_core(float ax, float y) {
+    // ---- log2(ax): range reduction on the binary32 bits (subnormals are scaled up first)
+    int e_adj = 0;
+    if (ax < 1.17549435e-38f) { ax = ax * 16777216.0f; e_adj = -24; }
+    uint32_t ix = f2u(ax);
+    int e = (int)(ix >> 23) - 127 + e_adj;
+    float zf = u2f((ix & 0x007FFFFFu) | 0x3F800000u);  // [1, 2)
+    if (zf >= 1.4609375f) { zf = zf * 0.5f; e += 1; }   // [187/256, 187/128)
+    int i = (int)(zf * 64.0f - 46.5f);                  // both operations exact
+    double z = (double)zf;
+    double r = __builtin_fma(z, orc_pow_logtab[2 * i], -1.0);
+    double p = orc_pow_logpoly[4];
+    p = __builtin_fma(p, r, orc_pow_logpoly[3]);
+    p = __builtin_fma(p, r, orc_pow_logpoly[2]);
+    p = __builtin_fma(p, r, orc_pow_logpoly[1]);
+    p = __builtin_fma(p, r, orc_pow_logpoly[0]);
+    double lg = __builtin_fma(p, r, (double)e + orc_pow_logtab[2 * i + 1]);
+    // ---- exp2(y * log2(ax))
+    double E = (double)y * lg;
+    if (!(std::fabs(E) < 160.0)) E = (E < 0.0) ? -160.0 : 160.0;  // beyond binary32's range either way (NaN cannot occur here)
+    const double SHIFT = 6755399441055744.0;  // 1.5 * 2^52: adding it rounds to an integer (round-to-nearest-even)
     double t = E * 32.0;
     double kd = (t + SHIFT) - SHIFT;
     int k = (int)kd;
-    double r = (t - kd) * 0.03125;
-    double p = orc_pow_exppoly[4];
-    p = p * r + orc_pow_exppoly[3];
-    p = p * r + orc_pow_exppoly[2];
-    p = p * r + orc_pow_exppoly[1];
-    p = p * r + orc_pow_exppoly[0];
-    int64_t q = (int64_t)(k >> 5);
-    double s = u2d(orc_pow_exp2bits[k & 31] + ((uint64_t)q << 52));
-    return s + s * (p * r);
-}
-
-static inline float pow_core(float ax, float y) {
-    double E = (double)y * pow_log2((double)ax);
-    if (E > 200.0) E = 200.0;
-    if (E < -200.0) E = -200.0;
-    return (float)pow_exp2(E);
+    double rr = t - kd;
+    double q = orc_pow_exppoly[3];
+    q = __builtin_fma(q, rr, orc_pow_exppoly[2]);
+    q = __builtin_fma(q, rr, orc_pow_exppoly[1]);
+    q = __builtin_fma(q, rr, orc_pow_exppoly[0]);
+    q = q * rr;
+    double s = u2d(orc_pow_exp2bits[k & 31] + ((uint64_t)(int64_t)(k >> 5) << 52));
+    return (float)__builtin_fma(s, q, s);
 }
 
 // 0: not an integer, 1: odd integer, 2: even integer (y finite, non-zero)

@@ -125,7 +125,8 @@ ABI_SYMBOLS = [
     "rt_abi_version",
 ]
 
-LIB_PATH = os.path.join(_HERE, "librt_mi355x.so")
+# RT_MI355X_LIB overrides the library file (used to A/B kernel builds); it is still a HIP build of this backend
+LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(_HERE, "librt_mi355x.so")
 HOST_LIB_PATH = os.path.join(_HERE, "librt_host.so")
 
 _lib = None

@@ -94,4 +94,5 @@ struct DevFrame {
     uint32_t *rgba;      // width*height packed R | G<<8 | B<<16 | A<<24
     float *accum;        // width*height float4
     uint32_t *counters;  // [gridDim.x][n_counters]
+    unsigned long long *diag;  // diagnostic builds only (RT_DIAG): per-section wave-cycle sums
 };

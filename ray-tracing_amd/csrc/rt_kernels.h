@@ -42,6 +42,25 @@ struct Cnt {
     RT_DEV void ray(int slot) { rays += 1u; if (EVENTS) ev[slot] += 1u; }
 };
 
+// Diagnostic build (-DRT_DIAG): wave-cycle stamps around the sections of rt_trace_kernel.  Never enabled in the
+// shipped library; the stamps serialise the instruction stream, so only the shares are meaningful.
+enum { DG_TOTAL = 0, DG_RAYGEN, DG_TRACE, DG_FINALIZE, DG_LIGHTS, DG_SHADOW_TRACE, DG_POW, DG_BLINN, DG_REFLRAY, DG_UNWIND, DG_STORE, DG_TEX, DG_N };
+#ifdef RT_DIAG
+struct Diag { uint32_t acc[DG_N]; };
+__device__ Diag *g_diag_unused;
+#define DG_DECL Diag dg; for (int i_ = 0; i_ < DG_N; i_++) dg.acc[i_] = 0u;
+#define DG_BEGIN(sec) const unsigned long long dgt_##sec = __builtin_amdgcn_s_memtime();
+#define DG_END(sec) dg.acc[sec] += (uint32_t)(__builtin_amdgcn_s_memtime() - dgt_##sec);
+#define DG_ARG , Diag &dg
+#define DG_PASS , dg
+#else
+#define DG_DECL
+#define DG_BEGIN(sec)
+#define DG_END(sec)
+#define DG_ARG
+#define DG_PASS
+#endif
+
 RT_DEV f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
 // (M * vec4(v, 0)).xyz and (M * vec4(v, 1)).xyz in glam's order: ((c0*x + c1*y) + c2*z) + c3*w
 RT_DEV f3 xf_dir(const DevXform &m, f3 v) {
@@ -415,12 +434,14 @@ RT_DEV void finalize_hit(const DevScene &S, f3 ro, f3 rd, float t, int obj, int 
 // shading
 // ------------------------------------------------------------------------------------------------
 // Ray::blinn_phong (src/ray.rs:68-85) with light.direction(hit.point) evaluated once (it is pure).
-RT_DEV f3 blinn_phong(f3 ray_dir, f3 normal, f3 ldir, f3 color, const Mtl &m) {
+RT_DEV f3 blinn_phong(f3 ray_dir, f3 normal, f3 ldir, f3 color, const Mtl &m, PowTab pow_tab DG_ARG) {
     float coeff = dot(normal, -ldir);
     f3 ambience = m.ambience * color;
     f3 diffuse = m.diffuse * rt_max(coeff, 0.0f) * color;
     f3 half_angle = normalize(-ray_dir - ldir);
-    float shininess = rt_powf(rt_max(dot(normal, half_angle), 0.0f), m.shininess);
+    DG_BEGIN(DG_POW)
+    float shininess = rt_powf(rt_max(dot(normal, half_angle), 0.0f), m.shininess, pow_tab);
+    DG_END(DG_POW)
     f3 specular = m.specular * shininess * color;
     return ambience + diffuse + specular;
 }
@@ -431,32 +452,40 @@ RT_DEV void light_dir_dist(const DevLight &l, f3 point, f3 &dir, float &dist) {
     else { f3 v = point - ld3(l.vec); float len = length(v); dir = v * (1.0f / len); dist = len; }
 }
 
-// RayTracing::light (src/ray_tracing/ray_tracing.rs:28-57)
+// RayTracing::light (src/ray_tracing/ray_tracing.rs:28-57).  The reference first sums all lights and then, per light,
+// halves the sum if the shadow ray towards it hits another object.  Every halving is the same exact operation (x 0.5),
+// so only their number matters: one loop shades a light and traces its shadow ray (its direction is computed once),
+// and the halvings are applied after the loop.
 template <bool EVENTS, bool BVH>
-RT_DEV f3 shade_lights(const DevScene &S, f3 ray_dir, const HitRec &h, f3 albedo, const Mtl &m, int obj_index, Cnt<EVENTS> &cnt) {
+RT_DEV f3 shade_lights(const DevScene &S, f3 ray_dir, const HitRec &h, f3 albedo, const Mtl &m, int obj_index, PowTab pow_tab, Cnt<EVENTS> &cnt DG_ARG) {
     cnt.add(RT_CNT_LIGHT_CALL);
     f3 l_acc = splat3(0.0f);
     const uint32_t nl = S.n_lights;
+    const bool shadows = S.shadow_casting != 0u;
+    const f3 so = h.point + RT_EPSILON * h.normal;
+    uint32_t occluded = 0u;
     for (uint32_t i = 0; i < nl; i++) {
         const DevLight &l = S.lights[i];
         cnt.add(RT_CNT_LIGHT_SHADE);
         f3 ldir; float ldist;
+        DG_BEGIN(DG_BLINN)
         light_dir_dist(l, h.point, ldir, ldist);
-        f3 k = blinn_phong(ray_dir, h.normal, ldir, albedo, m);
+        f3 k = blinn_phong(ray_dir, h.normal, ldir, albedo, m, pow_tab DG_PASS);
         l_acc = l_acc + (k / (ldist * ldist)) * ld3(l.albedo) * l.intensity;
-    }
-    if (S.shadow_casting) {
-        f3 so = h.point + RT_EPSILON * h.normal;
-        for (uint32_t i = 0; i < nl; i++) {
-            const DevLight &l = S.lights[i];
-            f3 ldir; float ldist;
-            light_dir_dist(l, h.point, ldir, ldist);
+        DG_END(DG_BLINN)
+        if (shadows) {
             float st; int ssub;
+            DG_BEGIN(DG_SHADOW_TRACE)
             int idx = trace_ray<EVENTS, BVH>(S, so, -ldir, st, ssub, cnt, RT_CNT_RAYS_SHADOW);
-            if (idx >= 0 && idx != obj_index) l_acc = l_acc * 0.5f;
+            DG_END(DG_SHADOW_TRACE)
+            if (idx >= 0 && idx != obj_index) occluded += 1u;
         }
     }
-    return vpowf(l_acc, 0.4166f);
+    for (uint32_t j = 0; j < occluded; j++) l_acc = l_acc * 0.5f;
+    DG_BEGIN(DG_POW)
+    f3 res = vpowf(l_acc, 0.4166f, pow_tab);
+    DG_END(DG_POW)
+    return res;
 }
 
 RT_DEV f3 rt_reflect(f3 vec, f3 normal) { return vec - (2.0f * dot(vec, normal)) * normal; }  // geometry.rs:7-9
@@ -580,23 +609,31 @@ enum { FK_REFL = 0, FK_REFR1 = 1, FK_REFR2 = 2, FK_PASS = 3 };
 //   BVH    : closest hits go through the bounding-volume hierarchy (scenes with many objects)
 //   dynamic LDS: max_ray_bounces * 4 * blockDim.x floats (reflective frames, one column per lane)
 // ------------------------------------------------------------------------------------------------
+// second launch bound = waves per SIMD: keeps the allocation at <= 128 VGPRs (4 waves per SIMD); the kernel is bound by
+// VALU issue and loses more from dropping to 3 waves than from the few values the allocator then has to re-compute
 template <bool EVENTS, bool REFR, int RDEPTH, bool BVH>
-__global__ void __launch_bounds__(256) rt_trace_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
+__global__ void __launch_bounds__(256, 4) rt_trace_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
     extern __shared__ float s_frames[];
     __shared__ uint32_t s_cnt[(EVENTS ? RT_CNT_COUNT : 0) + 1];
+    __shared__ __attribute__((aligned(16))) double s_pow[RT_POW_LDS_DOUBLES];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     for (uint32_t i = tid; i < (uint32_t)((EVENTS ? RT_CNT_COUNT : 0) + 1); i += nthr) s_cnt[i] = 0u;
+    rt_pow_lds_init(s_pow);
     __syncthreads();
 
     Cnt<EVENTS> cnt;
     cnt.clear();
+    DG_DECL
+    DG_BEGIN(DG_TOTAL)
     uint32_t px, py;
     if (lane_pixel(C, F, px, py)) {
         const uint32_t pos = py * C.width + px;
         cnt.add(RT_CNT_RAYGEN);
         cnt.add(RT_CNT_PIXEL_PACK);
         f3 ro = ld3(C.position);
+        DG_BEGIN(DG_RAYGEN)
         f3 rd = camera_ray(C, px, py);
+        DG_END(DG_RAYGEN)
         f3 L = splat3(0.0f);      // light_color carried down
         f3 Cc = splat3(1.0f);     // contribution carried down
         f3 V = splat3(0.0f);      // value returned by the subtree just finished
@@ -618,22 +655,32 @@ __global__ void __launch_bounds__(256) rt_trace_kernel(const DevScene S, const D
                 have_value = true;
             } else {
                 float t; int sub;
+                DG_BEGIN(DG_TRACE)
                 int obj = trace_ray<EVENTS, BVH>(S, ro, rd, t, sub, cnt, ray_slot);
+                DG_END(DG_TRACE)
                 if (obj < 0) {
                     V = L + ambient * Cc;
                     have_value = true;
                 } else {
                     HitRec h; Mtl m;
+                    DG_BEGIN(DG_FINALIZE)
                     finalize_hit<EVENTS, BVH>(S, ro, rd, t, obj, sub, h, m, cnt);
+                    DG_END(DG_FINALIZE)
                     f3 albedo = m.albedo;
                     if (m.kind == RT_REFLECTIVE) {
+                        DG_BEGIN(DG_TEX)
                         if (m.texture >= 0) { cnt.add(RT_CNT_TEX_FETCH); albedo = tex_from_uv(S.textures[m.texture], h.u, h.v); }
+                        DG_END(DG_TEX)
                         f3 p;
-                        if (!dmode) p = shade_lights<EVENTS, BVH>(S, rd, h, albedo, m, obj, cnt);
+                        DG_BEGIN(DG_LIGHTS)
+                        if (!dmode) p = shade_lights<EVENTS, BVH>(S, rd, h, albedo, m, obj, s_pow, cnt DG_PASS);
                         else p = L + m.emission_power * albedo;
+                        DG_END(DG_LIGHTS)
                         cnt.add(scene_diffuse ? RT_CNT_DIFFUSE_RAY : RT_CNT_REFLECTION_RAY);
                         f3 no, nd;
+                        DG_BEGIN(DG_REFLRAY)
                         rt_reflection_ray(rd, h, m.roughness, key, scene_diffuse, jitter, no, nd);
+                        DG_END(DG_REFLRAY)
                         if (!dmode) {
                             float *fr = s_frames + (size_t)(depth * 4u) * nthr + tid;
                             fr[0] = p.x; fr[nthr] = p.y; fr[2u * nthr] = p.z; fr[3u * nthr] = m.roughness;
@@ -655,7 +702,7 @@ __global__ void __launch_bounds__(256) rt_trace_kernel(const DevScene S, const D
                         f3 lo = h.point + RT_EPSILON * h.normal;
                         f3 ldv = rt_reflect(rd, h.normal);
                         f3 p;
-                        if (!dmode) p = shade_lights<EVENTS, BVH>(S, rd, h, albedo, m, obj, cnt);
+                        if (!dmode) p = shade_lights<EVENTS, BVH>(S, rd, h, albedo, m, obj, s_pow, cnt DG_PASS);
                         else p = L + m.emission_power * albedo;
                         f3 cchild = Cc * albedo;
                         float *f = rfr[depth];
@@ -686,6 +733,7 @@ __global__ void __launch_bounds__(256) rt_trace_kernel(const DevScene S, const D
                 }
             }
             // ---- unwind: feed V to the pending frames until a second child must be traced or the root returns
+            DG_BEGIN(DG_UNWIND)
             while (have_value) {
                 if (depth == 0u) { done = true; break; }
                 const uint32_t d = depth - 1u;
@@ -725,9 +773,19 @@ __global__ void __launch_bounds__(256) rt_trace_kernel(const DevScene S, const D
                     depth = d;
                 }
             }
+            DG_END(DG_UNWIND)
         }
+        DG_BEGIN(DG_STORE)
         store_pixel(F, pos, V);
+        DG_END(DG_STORE)
     }
+    DG_END(DG_TOTAL)
+#ifdef RT_DIAG
+    if ((threadIdx.x & 63u) == 0u && F.diag) {
+        const uint32_t gw_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        for (int i_ = 0; i_ < DG_N; i_++) F.diag[(size_t)gw_ * DG_N + i_] = (unsigned long long)dg.acc[i_];
+    }
+#endif
     flush_counters<EVENTS>(F, cnt, s_cnt);
 }
 
@@ -855,14 +913,17 @@ RT_DEV uint32_t rm_sdfs(const DevScene &S, f3 ro, f3 rd, float t, SdfOut &best, 
 }
 
 template <bool EVENTS>
-__global__ void __launch_bounds__(256) rt_march_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
+__global__ void __launch_bounds__(256, 6) rt_march_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
     __shared__ uint32_t s_cnt[(EVENTS ? RT_CNT_COUNT : 0) + 1];
+    __shared__ __attribute__((aligned(16))) double s_pow[RT_POW_LDS_DOUBLES];
     for (uint32_t i = threadIdx.x; i < (uint32_t)((EVENTS ? RT_CNT_COUNT : 0) + 1); i += blockDim.x) s_cnt[i] = 0u;
+    rt_pow_lds_init(s_pow);
     __syncthreads();
     Cnt<EVENTS> cnt;
     cnt.clear();
     Cnt<false> nocnt;
     nocnt.clear();
+    DG_DECL
     uint32_t px, py;
     if (lane_pixel(C, F, px, py)) {
         const uint32_t pos = py * C.width + px;
@@ -916,7 +977,7 @@ __global__ void __launch_bounds__(256) rt_march_kernel(const DevScene S, const D
                 f3 tx = tex_from_uv(tex, hit1.y * scale, hit1.z * scale);
                 f3 ty = tex_from_uv(tex, hit1.x * scale, hit1.z * scale);
                 f3 tz = tex_from_uv(tex, hit1.x * scale, hit1.y * scale);
-                f3 bw = vpowf(vabs(n1), 0.8f);
+                f3 bw = vpowf(vabs(n1), 0.8f, s_pow);
                 bw = bw / (bw.x + bw.y + bw.z);
                 albedo = tx * bw.x + ty * bw.y + tz * bw.z;
             }
@@ -928,10 +989,10 @@ __global__ void __launch_bounds__(256) rt_march_kernel(const DevScene S, const D
                 cnt.add(RT_CNT_LIGHT_SHADE);
                 f3 ldir; float ldist;
                 light_dir_dist(l, hitp, ldir, ldist);
-                f3 phong = blinn_phong(rd, n, ldir, albedo, m);
+                f3 phong = blinn_phong(rd, n, ldir, albedo, m, s_pow DG_PASS);
                 l_acc = l_acc + (phong / (ldist * ldist)) * ld3(l.albedo) * l.intensity;
             }
-            color = vpowf(l_acc, 0.4545f);
+            color = vpowf(l_acc, 0.4545f, s_pow);
             // occlusion (:141-158)
             float occ = 0.0f, sca = 1.0f;
 #pragma unroll

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -374,6 +375,15 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
     F.rgba = d_rgba8 ? (uint32_t *)d_rgba8 : c->rgba.ptr;
     F.accum = d_accum ? (float *)d_accum : c->accum.ptr;
     F.counters = c->counters.ptr;
+    F.diag = nullptr;
+#ifdef RT_DIAG
+    static unsigned long long *s_diag = nullptr;
+    static size_t s_diag_cap = 0;
+    const size_t diag_n = (size_t)n_waves * DG_N;
+    if (diag_n > s_diag_cap) { if (s_diag) (void)hipFree(s_diag); (void)hipMalloc((void **)&s_diag, diag_n * sizeof(unsigned long long)); s_diag_cap = diag_n; }
+    (void)hipMemsetAsync(s_diag, 0, diag_n * sizeof(unsigned long long), s);
+    F.diag = s_diag;
+#endif
 
     RT_HIP(c, hipEventRecord(c->ev0, s));
     if (S.ray_marching) {
@@ -399,6 +409,17 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
     RT_HIP(c, hipGetLastError());
     RT_HIP(c, hipEventRecord(c->ev1, s));
     c->last_blocks = blocks; c->last_ncnt = ncnt; c->last_events = events; c->timed = true; c->last_stream = s;
+#ifdef RT_DIAG
+    if (getenv("RT_DIAG_PRINT")) {
+        std::vector<unsigned long long> all((size_t)n_waves * DG_N);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(all.data(), F.diag, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long h[DG_N] = {0};
+        for (size_t w = 0; w < (size_t)n_waves; w++) for (int i = 0; i < DG_N; i++) h[i] += all[w * DG_N + i];
+        static const char *names[DG_N] = {"total", "raygen", "trace", "finalize", "lights(all)", "  shadow_trace", "  pow(blinn+gamma)", "  blinn(incl its pow)", "reflection_ray", "unwind", "store", "texture"};
+        for (int i = 0; i < DG_N; i++) fprintf(stderr, "DIAG %-24s %14llu wave-cycles %6.2f%%  (%.0f per wave)\n", names[i], h[i], 100.0 * (double)h[i] / (double)(h[0] ? h[0] : 1), (double)h[i] / (double)n_waves);
+    }
+#endif
     c->frames += 1;
     return RT_OK;
 }

@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B of kernel builds on the GPU box: tools/ab_variants.sh "<workloads>" lib1.so lib2.so ...
+WLS=$1; shift
+for r in 1 2; do
+for lib in "$@"; do
+  for wl in $WLS; do
+    RT_MI355X_LIB=$PWD/$lib timeout -k 10 120 python3 bench.py --workload $wl --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$lib', '$wl', 'ms', d['ms_per_step'], 'Mrays/s', d['value'], 'frac', d['roofline']['frac'])"
+  done
+done
+done
