@@ -6,7 +6,7 @@
 // unchanged, so the closest hit (and therefore every pixel) is identical to the linear scan's.
 //
 // Layout: nodes in depth-first order with a skip link (the node to continue with when the ray misses the box), so
-// the traversal needs no stack.  Boxes are inflated slightly: the candidate tests run in each object's own space,
+// the traversal needs no stack; one such layout per sign octant of the ray direction (see RtBvhBuilder).  Boxes are inflated slightly: the candidate tests run in each object's own space,
 // and a hit they report must never be culled by rounding in the world-space box test.
 #pragma once
 #include <algorithm>
@@ -79,59 +79,124 @@ inline bool rt_bvh_wanted(const rt_scene_desc *d) {
     return bounded >= kBvhMinObjects;
 }
 
+// Build: top-down, binned surface-area heuristic on the longest centroid axis (median split when the heuristic finds
+// no useful plane).  The tree is then written out EIGHT times, once per sign octant of the ray direction: in layout
+// `oct` every inner node is followed by the child that a ray of that octant enters first along the node's split
+// axis, then by the other child.  Near-first order lets `tmin <= closest` cull most of the far subtrees while the
+// traversal stays stackless (skip links).  All layouts share the leaf -> object index list.
+constexpr int kBvhBins = 16;
+constexpr uint32_t kBvhLayouts = 8;
+
 struct RtBvhBuilder {
-    const rt_scene_desc *d;
+    struct TreeNode { RtAabb box; int32_t left, right, axis; uint32_t first, count; };  // left < 0: leaf over prims[first, first + count)
     std::vector<RtAabb> boxes;
     std::vector<uint32_t> ids;  // bounded object indices, permuted during the build
-    std::vector<DevBvhNode> *nodes;
+    std::vector<TreeNode> tree;
     std::vector<uint32_t> *prims;
 
-    uint32_t build(uint32_t first, uint32_t count) {
+    static float half_area(const RtAabb &b) {
+        const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    float centroid2(uint32_t id, int axis) const { return boxes[id].lo[axis] + boxes[id].hi[axis]; }  // twice the centroid
+
+    int32_t build(uint32_t first, uint32_t count) {
         RtAabb box; box.reset();
-        RtAabb cbox; cbox.reset();
+        float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
         for (uint32_t i = first; i < first + count; i++) {
-            const RtAabb &b = boxes[ids[i]];
-            box.grow(b);
-            float c[3] = {0.5f * (b.lo[0] + b.hi[0]), 0.5f * (b.lo[1] + b.hi[1]), 0.5f * (b.lo[2] + b.hi[2])};
-            cbox.grow(c);
+            box.grow(boxes[ids[i]]);
+            for (int k = 0; k < 3; k++) { const float c = centroid2(ids[i], k); clo[k] = std::min(clo[k], c); chi[k] = std::max(chi[k], c); }
         }
-        const uint32_t me = (uint32_t)nodes->size();
-        nodes->push_back(DevBvhNode{});
-        DevBvhNode n;
-        for (int k = 0; k < 3; k++) { n.lo[k] = box.lo[k]; n.hi[k] = box.hi[k]; }
+        const int32_t me = (int32_t)tree.size();
+        tree.push_back(TreeNode{});
+        TreeNode n; n.box = box; n.left = n.right = -1; n.axis = 0; n.first = 0; n.count = 0;
         if (count <= kBvhLeafSize) {
             // ascending object index inside a leaf keeps the candidate order of the linear scan
             std::sort(ids.begin() + first, ids.begin() + first + count);
-            n.leaf = (int32_t)(((uint32_t)prims->size() << 4) | count);
+            n.first = (uint32_t)prims->size(); n.count = count;
             for (uint32_t i = first; i < first + count; i++) prims->push_back(ids[i]);
         } else {
             int axis = 0;
-            float ext = cbox.hi[0] - cbox.lo[0];
-            for (int k = 1; k < 3; k++) if (cbox.hi[k] - cbox.lo[k] > ext) { ext = cbox.hi[k] - cbox.lo[k]; axis = k; }
-            const uint32_t mid = first + count / 2;
-            std::nth_element(ids.begin() + first, ids.begin() + mid, ids.begin() + first + count, [&](uint32_t a, uint32_t b) {
-                float ca = boxes[a].lo[axis] + boxes[a].hi[axis], cb = boxes[b].lo[axis] + boxes[b].hi[axis];
-                return ca < cb || (ca == cb && a < b);
-            });
-            n.leaf = -1;
-            build(first, mid - first);
-            build(mid, first + count - mid);
+            for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+            uint32_t mid = first + count / 2;
+            bool split_done = false;
+            const float ext = chi[axis] - clo[axis];
+            if (ext > 0.0f && std::isfinite(ext)) {
+                RtAabb bin_box[kBvhBins]; uint32_t bin_n[kBvhBins];
+                for (int b = 0; b < kBvhBins; b++) { bin_box[b].reset(); bin_n[b] = 0; }
+                const float scale = (float)kBvhBins / ext;
+                auto bin_of = [&](uint32_t id) { int b = (int)((centroid2(id, axis) - clo[axis]) * scale); return std::min(std::max(b, 0), kBvhBins - 1); };
+                for (uint32_t i = first; i < first + count; i++) { const int b = bin_of(ids[i]); bin_box[b].grow(boxes[ids[i]]); bin_n[b]++; }
+                float right_area[kBvhBins]; RtAabb acc; acc.reset();
+                for (int b = kBvhBins - 1; b > 0; b--) { acc.grow(bin_box[b]); right_area[b] = half_area(acc); }  // only read where bins b.. are non-empty
+                acc.reset();
+                float best_cost = 3.0e38f; int best_plane = -1; uint32_t nl = 0;
+                for (int b = 0; b < kBvhBins - 1; b++) {  // plane after bin b
+                    if (bin_n[b]) acc.grow(bin_box[b]);
+                    nl += bin_n[b];
+                    const uint32_t nr = count - nl;
+                    if (nl == 0 || nr == 0) continue;
+                    const float cost = half_area(acc) * (float)nl + right_area[b + 1] * (float)nr;
+                    if (cost < best_cost) { best_cost = cost; best_plane = b; }
+                }
+                if (best_plane >= 0) {
+                    auto it = std::stable_partition(ids.begin() + first, ids.begin() + first + count, [&](uint32_t id) { return bin_of(id) <= best_plane; });
+                    mid = (uint32_t)(it - ids.begin());
+                    split_done = mid > first && mid < first + count;
+                }
+            }
+            if (!split_done) {
+                mid = first + count / 2;
+                std::nth_element(ids.begin() + first, ids.begin() + mid, ids.begin() + first + count, [&](uint32_t a, uint32_t b) {
+                    const float ca = centroid2(a, axis), cb = centroid2(b, axis);
+                    return ca < cb || (ca == cb && a < b);
+                });
+            }
+            n.axis = axis;
+            n.left = build(first, mid - first);           // lower centroids along `axis`
+            n.right = build(mid, first + count - mid);
         }
-        n.skip = (int32_t)nodes->size();  // first node after this subtree in depth-first order
-        (*nodes)[me] = n;
+        tree[(size_t)me] = n;
         return me;
+    }
+
+    // Depth-first layout for one sign octant (bit k of `oct` set: the ray direction's k-th component is negative).
+    void emit(int32_t t, uint32_t oct, std::vector<DevBvhNode> &out) const {
+        const TreeNode &n = tree[(size_t)t];
+        const size_t me = out.size();
+        out.push_back(DevBvhNode{});
+        DevBvhNode d;
+        for (int k = 0; k < 3; k++) { d.lo[k] = n.box.lo[k]; d.hi[k] = n.box.hi[k]; }
+        if (n.left < 0) {
+            d.leaf = (int32_t)((n.first << 4) | n.count);
+        } else {
+            d.leaf = -1;
+            const bool negative = (oct >> n.axis) & 1u;
+            emit(negative ? n.right : n.left, oct, out);
+            emit(negative ? n.left : n.right, oct, out);
+        }
+        d.skip = (int32_t)out.size();  // first node after this subtree (each layout is emitted into its own array)
+        out[me] = d;
     }
 };
 
-// nodes: depth-first with skip links; prims: object indices in leaf order; unbounded: objects tested linearly.
+// nodes: kBvhLayouts depth-first layouts of `nodes.size() / kBvhLayouts` nodes each, skip links relative to the layout's
+// first node; prims: object indices in leaf order; unbounded: objects tested linearly.
 inline void rt_bvh_build(const rt_scene_desc *d, std::vector<DevBvhNode> &nodes, std::vector<uint32_t> &prims, std::vector<uint32_t> &unbounded) {
     RtBvhBuilder B;
-    B.d = d; B.nodes = &nodes; B.prims = &prims;
+    B.prims = &prims;
     B.boxes.resize(d->n_objects);
     nodes.clear(); prims.clear(); unbounded.clear();
     for (uint32_t i = 0; i < d->n_objects; i++) {
         if (rt_object_bounds(d->objects[i], B.boxes[i])) B.ids.push_back(i);
         else if (d->objects[i].kind == RT_PLANE) unbounded.push_back(i);
     }
-    if (!B.ids.empty()) B.build(0, (uint32_t)B.ids.size());
+    if (B.ids.empty()) return;
+    B.build(0, (uint32_t)B.ids.size());
+    for (uint32_t oct = 0; oct < kBvhLayouts; oct++) {
+        std::vector<DevBvhNode> one;
+        one.reserve(B.tree.size());
+        B.emit(0, oct, one);
+        nodes.insert(nodes.end(), one.begin(), one.end());
+    }
 }

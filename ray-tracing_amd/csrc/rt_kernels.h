@@ -274,10 +274,13 @@ RT_DEV int trace_closest_bvh(const DevScene &S, f3 ro, f3 rd, float &t_out, int 
     }
     const f3 inv = 1.0f / rd;
     const int n_nodes = (int)S.n_bvh_nodes;
+    // one depth-first layout per sign octant of the direction: children are met near-first along each split axis
+    const uint32_t oct = (rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u);
+    const float4 *nodes = reinterpret_cast<const float4 *>(S.bvh_nodes) + (size_t)oct * (size_t)n_nodes * 2u;
     int i = 0;
     while (i < n_nodes) {
-        const float4 a = reinterpret_cast<const float4 *>(S.bvh_nodes)[2 * i];
-        const float4 b = reinterpret_cast<const float4 *>(S.bvh_nodes)[2 * i + 1];
+        const float4 a = nodes[2 * i];
+        const float4 b = nodes[2 * i + 1];
         cnt.add(RT_CNT_BVH_NODE);
         // slab test; fminf/fmaxf drop the NaNs of 0 * inf so such slabs do not cull
         const float tx0 = (a.x - ro.x) * inv.x, tx1 = (b.x - ro.x) * inv.x;

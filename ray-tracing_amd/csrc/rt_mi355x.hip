@@ -280,7 +280,7 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         RT_HIP(c, hipMemcpy(c->bvh_prims.ptr, prims.data(), prims.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         if (!unbounded.empty()) RT_HIP(c, hipMemcpy(c->unbounded.ptr, unbounded.data(), unbounded.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         S.bvh_nodes = c->bvh_nodes.ptr; S.bvh_prims = c->bvh_prims.ptr; S.unbounded = c->unbounded.ptr;
-        S.n_bvh_nodes = (uint32_t)nodes.size(); S.n_unbounded = (uint32_t)unbounded.size();
+        S.n_bvh_nodes = (uint32_t)(nodes.size() / kBvhLayouts); S.n_unbounded = (uint32_t)unbounded.size();
     }
     c->has_scene = true;
     return RT_OK;
