@@ -173,7 +173,10 @@ def main() -> None:
                        "rays_per_step_per_rank": int(rays_rank), "sharding": shard,
                        "parallelism": f"{shard}-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": None,
+                         "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": measured_traffic(args.workload),
+                         # the 157.3 TFLOP/s peak counts packed FMAs (4 flops per lane-instruction); bit-exact parity keeps
+                         # multiplies and adds unfused, so one flop per lane-instruction (a quarter of it) bounds this code
+                         "frac_of_unfused_unpacked_peak": round(achieved / (FP32_VALU_PEAK_TFLOPS / 4.0), 5),
                          "kernel": "rt_march_kernel" if scene.desc.ray_marching else "rt_trace_kernel",
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
                          "note": "FP32 vector (VALU) roofline: this path has no dense contraction, so no MFMA"},
@@ -185,6 +188,17 @@ def main() -> None:
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(workload: str):
+    """HBM bytes per launch of the workload's render kernel from the committed PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate rocprofv3 runs, read side doubled for gfx950), or None when the workload has not been profiled."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh).get(workload, {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(pkg, scene, width, height, accumulate) -> dict:

@@ -36,6 +36,18 @@ def main():
             out.append(f"  {k[:90]} (dispatches {len(next(iter(cs.values())))})")
             for c, v in sorted(cs.items()):
                 out.append(f"    {c} = {sum(v) / len(v):.1f}")
+    # HBM traffic per dispatch of the render kernels: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies
+    # 128-byte read requests at 64 bytes, so the read side is doubled.
+    traffic = defaultdict(dict)
+    for f in sorted(glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE") and "rt_" in r["Kernel_Name"]:
+                traffic[r["Kernel_Name"]].setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, cs in traffic.items():
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            rd = 2.0 * 1024.0 * sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
+            wr = 1024.0 * sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+            out.append(f"== HBM traffic per dispatch, {k[:90]}: read {rd:.0f} B (2 x FETCH_SIZE KiB), write {wr:.0f} B, total {rd + wr:.0f} B")
     print("\n".join(out))
 
 
