@@ -18,7 +18,7 @@
 #include "rt_dev_scene.h"
 
 constexpr uint32_t kBvhMinObjects = 32;  // below this the linear scan is faster
-constexpr uint32_t kBvhLeafSize = 4;
+constexpr uint32_t kBvhLeafSize = 1;  // one object per leaf measured fastest (a candidate test costs about five node visits)
 
 struct RtAabb {
     float lo[3], hi[3];
@@ -93,6 +93,7 @@ struct RtBvhBuilder {
     std::vector<uint32_t> ids;  // bounded object indices, permuted during the build
     std::vector<TreeNode> tree;
     std::vector<uint32_t> *prims;
+    std::vector<int> kinds;     // object kind by object index
 
     static float half_area(const RtAabb &b) {
         const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
@@ -168,7 +169,7 @@ struct RtBvhBuilder {
         DevBvhNode d;
         for (int k = 0; k < 3; k++) { d.lo[k] = n.box.lo[k]; d.hi[k] = n.box.hi[k]; }
         if (n.left < 0) {
-            d.leaf = (int32_t)((n.first << 4) | n.count);
+            d.leaf = (int32_t)(((uint32_t)kinds[(*prims)[n.first]] << 28) | (*prims)[n.first]);  // one object per leaf: kind and index
         } else {
             d.leaf = -1;
             const bool negative = (oct >> n.axis) & 1u;
@@ -181,12 +182,15 @@ struct RtBvhBuilder {
 };
 
 // nodes: kBvhLayouts depth-first layouts of `nodes.size() / kBvhLayouts` nodes each, skip links relative to the layout's
-// first node; prims: object indices in leaf order; unbounded: objects tested linearly.
-inline void rt_bvh_build(const rt_scene_desc *d, std::vector<DevBvhNode> &nodes, std::vector<uint32_t> &prims, std::vector<uint32_t> &unbounded) {
+// first node; unbounded: objects tested linearly.
+inline void rt_bvh_build(const rt_scene_desc *d, std::vector<DevBvhNode> &nodes, std::vector<uint32_t> &unbounded) {
+    std::vector<uint32_t> prims;  // object indices in leaf order
     RtBvhBuilder B;
     B.prims = &prims;
     B.boxes.resize(d->n_objects);
-    nodes.clear(); prims.clear(); unbounded.clear();
+    B.kinds.resize(d->n_objects);
+    for (uint32_t i = 0; i < d->n_objects; i++) B.kinds[i] = d->objects[i].kind;
+    nodes.clear(); unbounded.clear();
     for (uint32_t i = 0; i < d->n_objects; i++) {
         if (rt_object_bounds(d->objects[i], B.boxes[i])) B.ids.push_back(i);
         else if (d->objects[i].kind == RT_PLANE) unbounded.push_back(i);

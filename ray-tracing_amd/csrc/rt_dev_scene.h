@@ -59,7 +59,7 @@ struct DevBvhNode {
     float lo[3];
     int32_t skip;  // index of the first node after this subtree
     float hi[3];
-    int32_t leaf;  // -1: inner node (first child = this + 1); else (first_prim << 4) | prim_count
+    int32_t leaf;  // -1: inner node (first child = this + 1); else (object kind << 28) | object index
 };
 
 struct DevScene {
@@ -69,7 +69,6 @@ struct DevScene {
     const uint32_t *sdfs;
     const DevTexture *textures;
     const DevBvhNode *bvh_nodes;   // null: linear scan
-    const uint32_t *bvh_prims;     // object indices, leaf order
     const uint32_t *unbounded;     // objects outside the hierarchy (planes), tested linearly
     uint32_t n_bvh_nodes, n_unbounded;
     uint32_t n_objects, n_materials, n_lights, n_sdfs;

@@ -245,9 +245,9 @@ RT_DEV int trace_closest(const DevScene &S, f3 ro, f3 rd, float &t_out, int &sub
 
 // One candidate test with a per-lane object (the object index differs between lanes: vector loads, divergent switch).
 template <bool EVENTS>
-RT_DEV bool cand_any(const DevObject &o, f3 ro, f3 rd, float &t, int &sub, Cnt<EVENTS> &cnt) {
+RT_DEV bool cand_any(int kind, const DevObject &o, f3 ro, f3 rd, float &t, int &sub, Cnt<EVENTS> &cnt) {
     sub = 0;
-    switch (o.kind) {
+    switch (kind) {
         case RT_SPHERE: cnt.add(RT_CNT_TEST_SPHERE); return cand_sphere(o, ro, rd, t);
         case RT_TRIANGLE: cnt.add(RT_CNT_TEST_TRIANGLE); return cand_triangle(o, ro, rd, t);
         case RT_CUBOID: cnt.add(RT_CNT_TEST_CUBOID); return cand_cuboid(o, ro, rd, t);
@@ -290,15 +290,12 @@ RT_DEV int trace_closest_bvh(const DevScene &S, f3 ro, f3 rd, float &t_out, int 
         const float tmax = rt_min(rt_min(rt_max(tx0, tx1), rt_max(ty0, ty1)), rt_max(tz0, tz1));
         const bool hit = tmin <= tmax && tmin <= closest;
         const int leaf = __float_as_int(b.w);
-        if (hit && leaf >= 0) {
-            const int first = leaf >> 4, count = leaf & 15;
-            for (int k = 0; k < count; k++) {
-                const int idx = (int)S.bvh_prims[first + k];
-                float t = 0.0f;
-                int sub = 0;
-                if (cand_any<EVENTS>(S.objects[idx], ro, rd, t, sub, cnt) && t > 0.0f && (t < closest || (t == closest && idx < best))) {
-                    closest = t; best = idx; best_sub = sub;
-                }
+        if (hit && leaf >= 0) {  // one object per leaf: kind in the top bits, so its record is the only dependent load
+            const int idx = leaf & 0x0FFFFFFF;
+            float t = 0.0f;
+            int sub = 0;
+            if (cand_any<EVENTS>(leaf >> 28, S.objects[idx], ro, rd, t, sub, cnt) && t > 0.0f && (t < closest || (t == closest && idx < best))) {
+                closest = t; best = idx; best_sub = sub;
             }
         }
         i = hit ? i + 1 : __float_as_int(a.w);

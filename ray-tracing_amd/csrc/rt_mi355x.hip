@@ -54,7 +54,6 @@ struct rt_ctx {
     DevBuf<uint32_t> sdfs;
     DevBuf<DevTexture> textures;
     DevBuf<DevBvhNode> bvh_nodes;
-    DevBuf<uint32_t> bvh_prims;
     DevBuf<uint32_t> unbounded;
     DevBuf<uint32_t> tex_data[kMaxTextures];
     DevTexture h_textures[kMaxTextures] = {};
@@ -151,7 +150,7 @@ void rt_destroy(rt_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->objects.release(); c->materials.release(); c->lights.release(); c->sdfs.release(); c->textures.release();
-    c->bvh_nodes.release(); c->bvh_prims.release(); c->unbounded.release();
+    c->bvh_nodes.release(); c->unbounded.release();
     for (auto &t : c->tex_data) t.release();
     c->rgba.release(); c->accum.release(); c->counters.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -169,6 +168,7 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         return fail(c, RT_ERR_INVALID_ARGUMENT, "scene array pointer is null");
     if (d->n_textures > kMaxTextures) return fail(c, RT_ERR_UNSUPPORTED, "more than 64 texture slots");
     if (d->max_ray_bounces > kMaxBounces) return fail(c, RT_ERR_UNSUPPORTED, "max_ray_bounces above 32");
+    if (d->n_objects >= (1u << 28)) return fail(c, RT_ERR_UNSUPPORTED, "2^28 or more objects");  // hierarchy leaves pack kind and index in 32 bits
     // what the reference would panic on (index out of bounds), checked up front
     for (uint32_t i = 0; i < d->n_materials; i++) {
         const rt_material &m = d->materials[i];
@@ -268,18 +268,16 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.max_ray_bounces = d->max_ray_bounces; S.shadow_casting = d->shadow_casting; S.ray_marching = d->ray_marching;
     S.diffuse = d->diffuse; S.enable_accumulation = d->enable_accumulation;
 
-    // Large all-sphere scenes get a bounding-volume hierarchy; small or mixed scenes keep the reference's linear scan.
-    S.bvh_nodes = nullptr; S.bvh_prims = nullptr; S.unbounded = nullptr; S.n_bvh_nodes = 0; S.n_unbounded = 0;
+    // Scenes with many bounded objects get a bounding-volume hierarchy; small scenes keep the reference's linear scan.
+    S.bvh_nodes = nullptr; S.unbounded = nullptr; S.n_bvh_nodes = 0; S.n_unbounded = 0;
     if (!d->ray_marching && rt_bvh_wanted(d)) {
-        std::vector<DevBvhNode> nodes; std::vector<uint32_t> prims, unbounded;
-        rt_bvh_build(d, nodes, prims, unbounded);
+        std::vector<DevBvhNode> nodes; std::vector<uint32_t> unbounded;
+        rt_bvh_build(d, nodes, unbounded);
         RT_HIP(c, c->bvh_nodes.ensure(nodes.size()));
-        RT_HIP(c, c->bvh_prims.ensure(prims.size()));
         RT_HIP(c, c->unbounded.ensure(unbounded.size() ? unbounded.size() : 1));
         RT_HIP(c, hipMemcpy(c->bvh_nodes.ptr, nodes.data(), nodes.size() * sizeof(DevBvhNode), hipMemcpyHostToDevice));
-        RT_HIP(c, hipMemcpy(c->bvh_prims.ptr, prims.data(), prims.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         if (!unbounded.empty()) RT_HIP(c, hipMemcpy(c->unbounded.ptr, unbounded.data(), unbounded.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        S.bvh_nodes = c->bvh_nodes.ptr; S.bvh_prims = c->bvh_prims.ptr; S.unbounded = c->unbounded.ptr;
+        S.bvh_nodes = c->bvh_nodes.ptr; S.unbounded = c->unbounded.ptr;
         S.n_bvh_nodes = (uint32_t)(nodes.size() / kBvhLayouts); S.n_unbounded = (uint32_t)unbounded.size();
     }
     c->has_scene = true;
