@@ -88,6 +88,7 @@ struct DevCamera {
 struct DevFrame {
     uint32_t frame_index;
     uint32_t row_begin, row_end;
+    uint32_t leaf_slots;  // march kernel: object-space rays cached in LDS (0: none)
     int32_t accumulate;
     uint64_t seed;
     uint32_t *rgba;      // width*height packed R | G<<8 | B<<16 | A<<24

@@ -805,15 +805,40 @@ RT_DEV float rt_smooth_step(float e0, float e1, float x) {  // :29-32
     return t * t * (3.0f - 2.0f * t);
 }
 
+// The object-space ray of a leaf, (inv * ro, inv * rd), does not depend on the march parameter t, but the reference
+// recomputes it in every sdf() call (~40 of the ~50 operations of a sphere's sdf).  During the march loop of one
+// pixel the world ray is fixed, so the kernel computes each leaf's object-space ray once (rm_fill_cache) and keeps it
+// in LDS: the direction per lane (one column per lane), the origin once per workgroup (every primary ray starts at
+// the camera position).  Leaves are numbered in evaluation order, which is the same in every sdfs() call.
+constexpr uint32_t kMarchThreads = 256u;  // workgroup size of the march kernel (compile-time: LDS offsets become immediates)
+struct RayCache {
+    float *trd;        // this lane's column: component c of slot s at trd[(s * 3 + c) * kMarchThreads]
+    float *tro;        // workgroup-wide: component c of slot s at tro[s * 3 + c]
+    uint32_t slot;
+};
+template <bool CACHED>
+RT_DEV void leaf_ray(const DevObject &o, f3 ro, f3 rd, RayCache &rc, f3 &tro, f3 &trd) {
+    if (CACHED) {
+        const float *d = rc.trd + rc.slot * (3u * kMarchThreads);
+        const float *q = rc.tro + rc.slot * 3u;
+        trd = mk3(d[0], d[kMarchThreads], d[2u * kMarchThreads]);
+        tro = mk3(q[0], q[1], q[2]);
+        rc.slot += 1u;
+    } else {
+        trd = xf_dir(o.inv, rd); tro = xf_pt(o.inv, ro);
+    }
+}
+
 // Object3D::sdf (src/objects.rs:33-44).  FULL: also albedo and transformed_ray (needed at the final march
-// step only); LEVEL: remaining Union/Substraction nesting the instantiation can descend.
-template <bool EVENTS, bool FULL, int LEVEL>
+// step only); LEVEL: remaining Union/Substraction nesting the instantiation can descend; CACHED: object-space rays
+// come from the RayCache instead of being recomputed.
+template <bool EVENTS, bool FULL, int LEVEL, bool CACHED>
 struct Sdf {
-    static RT_DEV void eval(const DevScene &S, const DevObject &o, f3 ro, f3 rd, float t, SdfOut &out, Cnt<EVENTS> &cnt) {
+    static RT_DEV void eval(const DevScene &S, const DevObject &o, f3 ro, f3 rd, float t, SdfOut &out, Cnt<EVENTS> &cnt, RayCache &rc) {
         switch (o.kind) {
             case RT_SPHERE: {  // sphere.rs:72-82
                 cnt.add(RT_CNT_SDF_SPHERE);
-                f3 trd = xf_dir(o.inv, rd), tro = xf_pt(o.inv, ro);
+                f3 trd, tro; leaf_ray<CACHED>(o, ro, rd, rc, tro, trd);
                 f3 p = tro + trd * t;
                 out.dist = length(p) - o.p[0];
                 if (FULL) { out.albedo = ld3(S.materials[o.material].albedo); out.tro = tro; out.trd = trd; }
@@ -821,7 +846,7 @@ struct Sdf {
             }
             case RT_CUBOID: {  // cuboid.rs:53-70
                 cnt.add(RT_CNT_SDF_CUBOID);
-                f3 trd = xf_dir(o.inv, rd), tro = xf_pt(o.inv, ro);
+                f3 trd, tro; leaf_ray<CACHED>(o, ro, rd, rc, tro, trd);
                 f3 p = tro + trd * t;
                 const float corner_radius = 0.1f;
                 f3 q = vabs(p) - ld3(o.p) + corner_radius;
@@ -838,7 +863,7 @@ struct Sdf {
             }
             case RT_CYLINDER: {  // cylinder.rs:56-74
                 cnt.add(RT_CNT_SDF_CYLINDER);
-                f3 trd = xf_dir(o.inv, rd), tro = xf_pt(o.inv, ro);
+                f3 trd, tro; leaf_ray<CACHED>(o, ro, rd, rc, tro, trd);
                 f3 p = tro + trd * t;
                 const float corner_radius = 0.1f;
                 float dx = (rt_sqrt((p.x * p.x) + (p.z * p.z)) - o.p[0]) + corner_radius;
@@ -852,8 +877,8 @@ struct Sdf {
                 if constexpr (LEVEL > 0) {
                     cnt.add(RT_CNT_SDF_UNION);
                     SdfOut h1, h2;
-                    Sdf<EVENTS, FULL, LEVEL - 1>::eval(S, S.objects[o.first], ro, rd, t, h1, cnt);
-                    Sdf<EVENTS, FULL, LEVEL - 1>::eval(S, S.objects[o.second], ro, rd, t, h2, cnt);
+                    Sdf<EVENTS, FULL, LEVEL - 1, CACHED>::eval(S, S.objects[o.first], ro, rd, t, h1, cnt, rc);
+                    Sdf<EVENTS, FULL, LEVEL - 1, CACHED>::eval(S, S.objects[o.second], ro, rd, t, h2, cnt, rc);
                     out.dist = rt_smooth_union(h1.dist, h2.dist, 0.7f);
                     if (FULL) {
                         float i = rt_interpolation(h1.dist, h2.dist, 0.7f);
@@ -871,8 +896,8 @@ struct Sdf {
                     cnt.add(RT_CNT_SDF_SUBSTRACTION);
                     SdfOut h1, h2;
                     const DevObject &o1 = S.objects[o.first];
-                    Sdf<EVENTS, FULL, LEVEL - 1>::eval(S, o1, ro, rd, t, h1, cnt);
-                    Sdf<EVENTS, FULL, LEVEL - 1>::eval(S, S.objects[o.second], ro, rd, t, h2, cnt);
+                    Sdf<EVENTS, FULL, LEVEL - 1, CACHED>::eval(S, o1, ro, rd, t, h1, cnt, rc);
+                    Sdf<EVENTS, FULL, LEVEL - 1, CACHED>::eval(S, S.objects[o.second], ro, rd, t, h2, cnt, rc);
                     out.dist = rt_max(-h2.dist, h1.dist);
                     if (FULL) { out.albedo = ld3(S.materials[o1.material].albedo); out.tro = h2.tro; out.trd = h2.trd; }
                 } else {
@@ -889,9 +914,10 @@ struct Sdf {
 };
 
 // RayMarching::sdfs (src/ray_marching/ray_marching.rs:24-107); returns obj_idx
-template <bool EVENTS, bool FULL>
-RT_DEV uint32_t rm_sdfs(const DevScene &S, f3 ro, f3 rd, float t, SdfOut &best, Cnt<EVENTS> &cnt) {
+template <bool EVENTS, bool FULL, bool CACHED = false>
+RT_DEV uint32_t rm_sdfs(const DevScene &S, f3 ro, f3 rd, float t, SdfOut &best, Cnt<EVENTS> &cnt, RayCache &rc) {
     cnt.add(RT_CNT_SDFS_CALL);
+    rc.slot = 0u;
     best.dist = RT_F32_MAX;
     best.albedo = splat3(0.0f); best.tro = splat3(0.0f); best.trd = splat3(0.0f);
     uint32_t obj_idx = 0u;
@@ -902,7 +928,7 @@ RT_DEV uint32_t rm_sdfs(const DevScene &S, f3 ro, f3 rd, float t, SdfOut &best, 
         const int kind = o.kind;
         if (kind == RT_TRIANGLE || kind == RT_CONE) continue;  // the `_ => {}` arm (:95)
         SdfOut d;
-        Sdf<EVENTS, FULL, 2>::eval(S, o, ro, rd, t, d, cnt);
+        Sdf<EVENTS, FULL, 2, CACHED>::eval(S, o, ro, rd, t, d, cnt, rc);
         if (d.dist < best.dist) {
             best.dist = d.dist;
             if (FULL) { best.albedo = d.albedo; best.tro = d.tro; best.trd = d.trd; }
@@ -912,25 +938,66 @@ RT_DEV uint32_t rm_sdfs(const DevScene &S, f3 ro, f3 rd, float t, SdfOut &best, 
     return obj_idx;
 }
 
-template <bool EVENTS>
+// Fills the RayCache for the world ray (ro, rd): visits the leaves in the order Sdf::eval does and stores their
+// object-space rays.  ro is the same for every lane of the workgroup; thread 0 stores the transformed origins.
+template <int LEVEL>
+RT_DEV void rm_fill_leaf(const DevScene &S, const DevObject &o, f3 ro, f3 rd, RayCache &rc) {
+    switch (o.kind) {
+        case RT_SPHERE: case RT_CUBOID: case RT_CYLINDER: {
+            const f3 trd = xf_dir(o.inv, rd), tro = xf_pt(o.inv, ro);
+            float *d = rc.trd + rc.slot * (3u * kMarchThreads);
+            d[0] = trd.x; d[kMarchThreads] = trd.y; d[2u * kMarchThreads] = trd.z;
+            if (threadIdx.x == 0u) { float *q = rc.tro + rc.slot * 3u; q[0] = tro.x; q[1] = tro.y; q[2] = tro.z; }
+            rc.slot += 1u;
+            break;
+        }
+        case RT_UNION: case RT_SUBSTRACTION:
+            if constexpr (LEVEL > 0) {
+                rm_fill_leaf<LEVEL - 1>(S, S.objects[o.first], ro, rd, rc);
+                rm_fill_leaf<LEVEL - 1>(S, S.objects[o.second], ro, rd, rc);
+            }
+            break;
+        default: break;  // plane: no transform; cone / triangle: no sdf
+    }
+}
+RT_DEV void rm_fill_cache(const DevScene &S, f3 ro, f3 rd, RayCache &rc) {
+    rc.slot = 0u;
+    const uint32_t n = S.n_sdfs;
+    for (uint32_t k = 0; k < n; k++) {
+        const DevObject &o = S.objects[S.sdfs[k]];
+        if (o.kind == RT_TRIANGLE || o.kind == RT_CONE) continue;
+        rm_fill_leaf<2>(S, o, ro, rd, rc);
+    }
+}
+
+// CACHE: the march loop reads the leaves' object-space rays from LDS (dynamic LDS: n_leaf_slots * 3 * (kMarchThreads + 1)
+// floats); chosen by the host when the scene's leaf count fits.  Launched with kMarchThreads threads per workgroup.
+template <bool EVENTS, bool CACHE>
 __global__ void __launch_bounds__(256, 6) rt_march_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
+    extern __shared__ float s_ray[];
     __shared__ uint32_t s_cnt[(EVENTS ? RT_CNT_COUNT : 0) + 1];
     __shared__ __attribute__((aligned(16))) double s_pow[RT_POW_LDS_DOUBLES];
     for (uint32_t i = threadIdx.x; i < (uint32_t)((EVENTS ? RT_CNT_COUNT : 0) + 1); i += blockDim.x) s_cnt[i] = 0u;
     rt_pow_lds_init(s_pow);
-    __syncthreads();
     Cnt<EVENTS> cnt;
     cnt.clear();
     Cnt<false> nocnt;
     nocnt.clear();
     DG_DECL
     uint32_t px, py;
-    if (lane_pixel(C, F, px, py)) {
+    const bool in_frame = lane_pixel(C, F, px, py);
+    const f3 ro = ld3(C.position);
+    const f3 rd = camera_ray(C, px, py);  // lanes outside the frame compute a direction nobody uses
+    RayCache rc;
+    rc.slot = 0u;
+    rc.trd = s_ray + threadIdx.x;
+    rc.tro = s_ray + F.leaf_slots * (3u * kMarchThreads);
+    if (CACHE) rm_fill_cache(S, ro, rd, rc);
+    __syncthreads();
+    if (in_frame) {
         const uint32_t pos = py * C.width + px;
         cnt.add(RT_CNT_RAYGEN);
         cnt.add(RT_CNT_PIXEL_PACK);
-        const f3 ro = ld3(C.position);
-        const f3 rd = camera_ray(C, px, py);
         f3 color = ld3(S.ambient);  // miss: ambient_color, no fade (:252)
         // march_ray (:181-203)
         cnt.ray(RT_CNT_RAYS_MARCH);
@@ -940,7 +1007,7 @@ __global__ void __launch_bounds__(256, 6) rt_march_kernel(const DevScene S, cons
             if (t > 40.0f) break;
             cnt.add(RT_CNT_MARCH_STEP);
             SdfOut d;
-            rm_sdfs<EVENTS, false>(S, ro, rd, t, d, cnt);
+            rm_sdfs<EVENTS, false, CACHE>(S, ro, rd, t, d, cnt, rc);
             t_eval = t;
             t = t + d.dist;
             if (d.dist < 0.001f) { hit = true; break; }
@@ -949,18 +1016,23 @@ __global__ void __launch_bounds__(256, 6) rt_march_kernel(const DevScene S, cons
             cnt.add(RT_CNT_MARCH_SHADE);
             // the final step again with albedo / transformed_ray / object index (same inputs, same values)
             SdfOut rh;
-            const uint32_t obj_idx = rm_sdfs<false, true>(S, ro, rd, t_eval, rh, nocnt);
+            const uint32_t obj_idx = rm_sdfs<false, true, CACHE>(S, ro, rd, t_eval, rh, nocnt, rc);
             const float distance = t;
             f3 hitp = ro + rd * distance;
             // normal (:109-139)
             const float k = 0.5773f * 0.0005f;
             const f3 xyy = mk3(1.0f, -1.0f, -1.0f), yyx = mk3(-1.0f, -1.0f, 1.0f), yxy = mk3(-1.0f, 1.0f, -1.0f), xxx = mk3(1.0f, 1.0f, 1.0f);
-            SdfOut a, b, c, d4;
-            rm_sdfs<EVENTS, false>(S, hitp, xyy, k, a, cnt);
-            rm_sdfs<EVENTS, false>(S, hitp, yyx, k, b, cnt);
-            rm_sdfs<EVENTS, false>(S, hitp, yxy, k, c, cnt);
-            rm_sdfs<EVENTS, false>(S, hitp, xxx, k, d4, cnt);
-            f3 n = normalize(xyy * a.dist + yyx * b.dist + yxy * c.dist + xxx * d4.dist);
+            // four taps in a loop (one copy of the sdfs code); the sum keeps the reference's order ((a + b) + c) + d
+            f3 nsum = splat3(0.0f);
+#pragma unroll 1
+            for (int tap = 0; tap < 4; tap++) {
+                const f3 e = tap == 0 ? xyy : (tap == 1 ? yyx : (tap == 2 ? yxy : xxx));
+                SdfOut a;
+                rm_sdfs<EVENTS, false>(S, hitp, e, k, a, cnt, rc);
+                const f3 term = e * a.dist;
+                nsum = tap == 0 ? term : nsum + term;
+            }
+            f3 n = normalize(nsum);
             // material of the winning object (:212-214); the index differs per lane: vector loads
             const DevObject *po = S.objects + obj_idx;
             const int okind = po->kind;
@@ -995,12 +1067,12 @@ __global__ void __launch_bounds__(256, 6) rt_march_kernel(const DevScene S, cons
             color = vpowf(l_acc, 0.4545f, s_pow);
             // occlusion (:141-158)
             float occ = 0.0f, sca = 1.0f;
-#pragma unroll
+#pragma unroll 1
             for (int i = 0; i < 3; i++) {
                 cnt.add(RT_CNT_OCCLUSION_TAP);
                 float hr = 0.02f + 0.025f * (float)(i * i);
                 SdfOut dd;
-                rm_sdfs<EVENTS, false>(S, hitp, n, hr, dd, cnt);
+                rm_sdfs<EVENTS, false>(S, hitp, n, hr, dd, cnt, rc);
                 occ = occ + (-(dd.dist - hr)) * sca;
                 sca = sca * 0.85f;
             }

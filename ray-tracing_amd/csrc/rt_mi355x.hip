@@ -63,6 +63,7 @@ struct rt_ctx {
     DevScene scene = {};
     DevCamera camera = {};
     bool has_scene = false, has_camera = false, has_refractive = false;
+    uint32_t leaf_slots = 0;  // ray-marching scenes: leaves per sdfs() call with an object-space ray
 
     DevBuf<uint32_t> rgba;
     DevBuf<float> accum;
@@ -108,12 +109,28 @@ int composite_depth(const rt_scene_desc *d, uint32_t i, int guard) {
     return 1 + (a > b ? a : b);
 }
 
+// Leaves whose object-space ray the march kernel can cache, counted the way Sdf::eval / rm_fill_leaf visit them
+// (`level` = remaining composite nesting).
+uint32_t march_leaf_slots(const rt_scene_desc *d, uint32_t i, int level) {
+    const rt_object &o = d->objects[i];
+    switch (o.kind) {
+        case RT_SPHERE: case RT_CUBOID: case RT_CYLINDER: return 1u;
+        case RT_UNION: case RT_SUBSTRACTION:
+            return level > 0 ? march_leaf_slots(d, (uint32_t)o.first, level - 1) + march_leaf_slots(d, (uint32_t)o.second, level - 1) : 0u;
+        default: return 0u;
+    }
+}
+
 // A render may have been launched on a caller's stream; anything that touches the same buffers from another
 // stream waits for it first.
 hipError_t wait_external(rt_ctx *c, hipStream_t next) {
     if (c->timed && c->last_stream != next) return hipStreamSynchronize(c->last_stream);
     return hipSuccess;
 }
+
+#ifndef RT_MARCH_CACHE_MAX_SLOTS
+#define RT_MARCH_CACHE_MAX_SLOTS 16
+#endif
 
 template <typename K>
 void launch(K kernel, uint32_t blocks, uint32_t threads, size_t lds, hipStream_t s, const DevScene &S, const DevCamera &C, const DevFrame &F) {
@@ -283,6 +300,14 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         S.bvh_nodes = c->bvh_nodes.ptr; S.unbounded = c->unbounded.ptr;
         S.n_bvh_nodes = (uint32_t)(nodes.size() / kBvhLayouts); S.n_unbounded = (uint32_t)unbounded.size();
     }
+    c->leaf_slots = 0;
+    if (d->ray_marching) {
+        for (uint32_t k = 0; k < d->n_sdfs; k++) {
+            const int kind = d->objects[d->sdfs[k]].kind;
+            if (kind == RT_TRIANGLE || kind == RT_CONE) continue;
+            c->leaf_slots += march_leaf_slots(d, d->sdfs[k], 2);
+        }
+    }
     c->has_scene = true;
     return RT_OK;
 }
@@ -363,7 +388,7 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
     const bool events = p->collect_events != 0;
     const uint32_t maxd = S.max_ray_bounces;
     // 256-thread workgroups keep max_ray_bounces * 4 KiB of reflective frames in LDS; deeper recursions use one wave per workgroup
-    const uint32_t threads = (maxd <= 8u) ? 256u : 64u;
+    const uint32_t threads = (S.ray_marching || maxd <= 8u) ? 256u : 64u;
     const uint32_t waves_per_block = threads / 64u;
     const uint32_t tiles_x = (c->camera.width + 7u) / 8u, tiles_y = (re - rb + 7u) / 8u;
     const uint64_t n_waves = (uint64_t)tiles_x * tiles_y;
@@ -372,7 +397,7 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
     RT_HIP(c, c->counters.ensure((size_t)blocks * ncnt));
 
     DevFrame F;
-    F.frame_index = p->frame_index; F.row_begin = rb; F.row_end = re; F.accumulate = p->accumulate; F.seed = p->seed;
+    F.frame_index = p->frame_index; F.row_begin = rb; F.row_end = re; F.leaf_slots = 0; F.accumulate = p->accumulate; F.seed = p->seed;
     F.rgba = d_rgba8 ? (uint32_t *)d_rgba8 : c->rgba.ptr;
     F.accum = d_accum ? (float *)d_accum : c->accum.ptr;
     F.counters = c->counters.ptr;
@@ -388,8 +413,17 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
 
     RT_HIP(c, hipEventRecord(c->ev0, s));
     if (S.ray_marching) {
-        if (events) launch(rt_march_kernel<true>, blocks, threads, 0, s, S, c->camera, F);
-        else launch(rt_march_kernel<false>, blocks, threads, 0, s, S, c->camera, F);
+        // up to 16 leaves (48 KiB of LDS per workgroup) keep their object-space rays in LDS during the march loop
+        const bool cache = c->leaf_slots >= 1u && c->leaf_slots <= (uint32_t)RT_MARCH_CACHE_MAX_SLOTS;
+        F.leaf_slots = cache ? c->leaf_slots : 0u;
+        const size_t lds = cache ? (size_t)c->leaf_slots * 3u * (threads + 1u) * sizeof(float) : 0u;
+        if (cache) {
+            if (events) launch(rt_march_kernel<true, true>, blocks, threads, lds, s, S, c->camera, F);
+            else launch(rt_march_kernel<false, true>, blocks, threads, lds, s, S, c->camera, F);
+        } else {
+            if (events) launch(rt_march_kernel<true, false>, blocks, threads, 0, s, S, c->camera, F);
+            else launch(rt_march_kernel<false, false>, blocks, threads, 0, s, S, c->camera, F);
+        }
     } else {
         const size_t lds = (size_t)(maxd ? maxd : 1u) * 4u * threads * sizeof(float);
         // kernel variant: bit 0 events, bits 1-2 refractive frames (0 none, 1 up to 8, 2 up to 32), bit 3 hierarchy
