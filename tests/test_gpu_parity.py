@@ -175,6 +175,35 @@ def test_nested_composites_and_substraction_in_the_sdf_list(pkg, orc, ctx):
         assert {k: st[k] for k in pkg.COUNTER_NAMES} == dict(zip(pkg.COUNTER_NAMES, ref["counters"]))
 
 
+@pytest.mark.parametrize("case", ["plane_only", "three_leaves", "sixteen_leaves", "seventeen_leaves"])
+def test_march_kernel_with_and_without_the_object_space_ray_cache(pkg, orc, ctx, case):
+    """The march loop keeps up to 16 leaves' object-space rays in LDS and recomputes them beyond that (or with none)."""
+    mats = [make_material(pkg, albedo=(0.9, 0.7, 0.5)), make_material(pkg, albedo=(0.2, 0.5, 0.9), shininess=40.0)]
+    objs = [make_object(pkg, pkg.RT_PLANE, 0, normal=(0, 1, 0), point=(0, 0, 0))]
+    n_leaves = {"plane_only": 0, "three_leaves": 3, "sixteen_leaves": 16, "seventeen_leaves": 17}[case]
+    kinds = [pkg.RT_SPHERE, pkg.RT_CUBOID, pkg.RT_CYLINDER]
+    for i in range(n_leaves):
+        x, z = -3.0 + 1.5 * (i % 5), -1.0 - 1.4 * (i // 5)
+        kind = kinds[i % 3]
+        if kind == pkg.RT_SPHERE:
+            objs.append(make_object(pkg, kind, 1, position=(x, 0.6, z), radius=0.5))
+        elif kind == pkg.RT_CUBOID:
+            objs.append(make_object(pkg, kind, 1, position=(x, 0.6, z), rotation_axis=(0, 20.0 * i, 0), dimension=(0.4, 0.5, 0.3)))
+        else:
+            objs.append(make_object(pkg, kind, 1, position=(x, 0.7, z), rotation_axis=(0, 0, 15.0 * i), radius=0.3, height=0.9))
+    lights = [make_light(pkg, kind=0, albedo=(1.0, 1.0, 1.0), vec=(-0.4, -0.8, -0.4), intensity=2.0)]
+    sb = SceneBuilder(pkg, objs, mats, lights, sdfs=list(range(len(objs))), ray_marching=1, max_ray_bounces=4)
+    cam = pkg.make_camera((0.0, 2.5, 5.0), (0.0, -0.3, -1.0), 160, 96)
+    ctx.set_scene(sb.desc)
+    ctx.set_camera(cam)
+    rgba, lin, st = gpu_frame(ctx, events=True)
+    ref = orc.render(sb.desc, cam, [], want_counters=True, n_threads=8)
+    assert_parity(rgba, ref["rgba"], lin, ref["accum"], what=case)
+    assert {k: st[k] for k in pkg.COUNTER_NAMES} == dict(zip(pkg.COUNTER_NAMES, ref["counters"]))
+    rgba2, lin2, _ = gpu_frame(ctx, events=False)   # the timed (non-counting) variant gives the same frame
+    assert np.array_equal(rgba2, rgba) and np.array_equal(lin2.view(np.uint32), lin.view(np.uint32))
+
+
 def test_row_bands_compose_the_full_frame(pkg, ctx):
     """Row-band sharding (one band per GPU): bands rendered separately equal the full frame, rays add up."""
     s = pkg.Scene("scene1")
