@@ -100,11 +100,21 @@ def main() -> None:
             if world > 1:
                 rgba.copy_(pkg.gather_row_bands(dist, rgba, height, rank, world))
         else:
-            # the spp samples of one accumulated frame are split by sample index; one all-reduce of the accumulators,
-            # then every rank resolves (divide, clamp, pack) the rows it owns
+            # the spp samples of one accumulated frame are split by sample index; a reduce-scatter leaves each rank with
+            # the summed rows it owns, which it resolves (divide, clamp, pack); the RGBA8 bands are then all-gathered
             accum.zero_()
-            pkg.render_sample_sharded(dist if world > 1 else None, lambda idx: render(idx, acc=True), accum, spp, rank, world, first_index=1 + i * spp)
-            ctx.resolve_device(spp, rows=my_rows, d_accum=accum.data_ptr(), d_rgba8=rgba.data_ptr(), stream=sh)
+            for idx in pkg.shard_samples(spp, rank, world, 1 + i * spp):
+                render(idx, acc=True)
+            rb, re, band = pkg.reduce_scatter_accumulators(dist if world > 1 else None, accum, rank, world)
+            if band.data_ptr() == accum.data_ptr() + rb * width * 16:
+                # all-reduce fallback or single GPU: the band is a slice of the full accumulator
+                ctx.resolve_device(spp, rows=(rb, re), d_accum=accum.data_ptr(), d_rgba8=rgba.data_ptr(), stream=sh)
+                if world > 1:
+                    rgba.copy_(pkg.gather_row_bands(dist, rgba, height, rank, world))
+            else:
+                # the band is its own tensor: resolve it as rows [0, re - rb) straight into this rank's rows of the frame
+                ctx.resolve_device(spp, rows=(0, re - rb), d_accum=band.data_ptr(), d_rgba8=rgba.data_ptr() + rb * width * 4, stream=sh)
+                pkg.gather_equal_bands(dist, rgba[rb:re], rgba)
 
     def rays_of_step(i: int) -> int:
         """Rays this rank traces in step i (untimed pass: one stats read-back per render)."""
@@ -181,6 +191,9 @@ def main() -> None:
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
                          "note": "FP32 vector (VALU) roofline: this path has no dense contraction, so no MFMA"},
         }
+        if scene.desc.ray_marching:
+            # one sdfs() call evaluates the whole SDF list once (src/ray_marching/ray_marching.rs:24-107)
+            out["config"]["sdf_list_evals_per_s"] = round(st["sdfs_call"] / (kernel_ms * 1e-3), 1)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, scene, width, height, accumulate)
         print(json.dumps(out), flush=True)

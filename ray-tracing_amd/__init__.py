@@ -383,4 +383,5 @@ class Context:
             pass
 
 
-from .sharding import gather_row_bands, render_sample_sharded, shard_rows, shard_samples  # noqa: E402,F401
+from .sharding import (equal_row_bands, gather_equal_bands, gather_row_bands, reduce_scatter_accumulators,  # noqa: E402,F401
+                       render_sample_sharded, shard_rows, shard_samples)

@@ -6,8 +6,9 @@ samples are independent, so the work shards without any exchange inside the per-
 * rows     each rank renders a contiguous band of rows of the same frame; the bands are disjoint ranges of the frame
            buffer, so the only collective is an all-gather of RGBA8 bands when one rank needs the whole frame.
 * samples  each rank renders a subset of the sample indices of an accumulated frame into its own accumulator
-           (Renderer.accumulated, src/renderer.rs:14,59-66); one all-reduce(sum) of the f32 accumulators, then every
-           rank resolves (divide by the sample count, clamp, pack) the rows it owns.
+           (Renderer.accumulated, src/renderer.rs:14,59-66); one reduce-scatter(sum) of the f32 accumulators leaves
+           every rank with the summed rows it owns (half the traffic of an all-reduce), it resolves them (divide by
+           the sample count, clamp, pack), and the RGBA8 bands are all-gathered (1/4 of the accumulator's bytes).
 * frames   whole frames of a sequence go to different ranks; no collective.
 
 The functions take a `render` callable so that the same logic drives the HIP backend (bench.py) and, in the CPU tests,
@@ -61,3 +62,34 @@ def render_sample_sharded(dist, render: Callable[[int], None], accum, n_samples:
     if world_size > 1 and dist is not None:
         dist.all_reduce(accum)
     return len(mine)
+
+
+def equal_row_bands(height: int, world_size: int) -> bool:
+    """True when the frame splits into `world_size` bands of the same number of rows (what reduce-scatter needs)."""
+    return world_size >= 1 and height % world_size == 0
+
+
+def reduce_scatter_accumulators(dist, accum, rank: int, world_size: int):
+    """Sums the (h, w, 4) f32 accumulators of all ranks; returns (row_begin, row_end, band) where `band` holds the
+    summed rows [row_begin, row_end) of this rank.  Equal bands go through one reduce-scatter; otherwise (or when the
+    backend lacks it) an all-reduce followed by a slice, with the 8-row-aligned bands of shard_rows."""
+    import torch
+    h = int(accum.shape[0])
+    if world_size == 1 or dist is None:
+        return 0, h, accum
+    if equal_row_bands(h, world_size):
+        rows = h // world_size
+        band = torch.empty((rows,) + tuple(accum.shape[1:]), dtype=accum.dtype, device=accum.device)
+        try:
+            dist.reduce_scatter_tensor(band, accum)
+            return rank * rows, (rank + 1) * rows, band
+        except (RuntimeError, NotImplementedError):
+            pass
+    dist.all_reduce(accum)
+    b, e = shard_rows(h, rank, world_size)
+    return b, e, accum[b:e]
+
+
+def gather_equal_bands(dist, band_rgba, full_rgba) -> None:
+    """All-gather of equal RGBA8 row bands (rank order = row order) into `full_rgba` on every rank."""
+    dist.all_gather_into_tensor(full_rgba, band_rgba)

@@ -37,6 +37,30 @@ def _worker(rank, world, port, mode, out_dir):
         local = torch.from_numpy(r["rgba"])
         full = pkg.gather_row_bands(dist, local, h, rank, world)
         np.save(os.path.join(out_dir, f"rows_{rank}.npy"), full.numpy())
+    elif mode in ("scatter", "scatter_ragged"):
+        # sample sharding as bench.py drives it: reduce-scatter of accumulators, resolve of the owned rows, all-gather of RGBA8
+        if mode == "scatter_ragged":
+            h = 75   # not divisible by 2: falls back to all-reduce + 8-row-aligned bands
+        s = pkg.Scene("scene2")
+        cam = s.camera(w, h)
+        acc = np.zeros((h, w, 4), dtype=np.float32)
+        acc_t = torch.from_numpy(acc)
+        for idx in pkg.shard_samples(6, rank, world):
+            orc.render(s.desc, cam, (), frame_index=idx, accumulate=True, seed=0x5EED, accum=acc)
+        rb, re, band = pkg.reduce_scatter_accumulators(dist, acc_t, rank, world)
+        assert (re - rb) == band.shape[0] and 0 <= rb < re <= h
+        # resolve as render_chunk's accumulation tail does (src/renderer.rs:62-66, :29-36)
+        lin = np.clip(band.numpy() / np.float32(6.0), 0.0, 1.0)
+        rgba_band = np.stack([(lin[..., 0] * 255.0).astype(np.uint8), (lin[..., 1] * 255.0).astype(np.uint8),
+                              (lin[..., 2] * 255.0).astype(np.uint8), np.full(lin.shape[:2], 255, np.uint8)], axis=-1)
+        full = torch.zeros((h, w, 4), dtype=torch.uint8)
+        full[rb:re] = torch.from_numpy(rgba_band)
+        if pkg.equal_row_bands(h, world):
+            pkg.gather_equal_bands(dist, full[rb:re].contiguous(), full)
+        else:
+            full = pkg.gather_row_bands(dist, full, h, rank, world)
+        np.save(os.path.join(out_dir, f"{mode}_{rank}.npy"), full.numpy())
+        np.save(os.path.join(out_dir, f"{mode}_band_{rank}.npy"), np.array([rb, re]))
     else:
         s = pkg.Scene("scene2")
         cam = s.camera(w, h)
@@ -74,6 +98,27 @@ def test_two_ranks_gloo(pkg, orc, tmp_path, mode):
         # same six samples, summed in a different order: relative 1e-6, far inside the 1e-3 linear budget after /6
         assert np.allclose(a, acc, rtol=1e-6, atol=1e-6)
         assert a[..., 3].min() == 6.0 and a[..., 3].max() == 6.0
+
+
+@pytest.mark.parametrize("mode", ["scatter", "scatter_ragged"])
+def test_two_ranks_reduce_scatter_resolve_all_gather(pkg, orc, tmp_path, mode):
+    """Sample sharding end to end: both ranks end with the same full RGBA8 frame, within 1 LSB of the single-process one."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, mode, str(tmp_path)), nprocs=2, join=True)
+    w, h = 96, (72 if mode == "scatter" else 75)
+    s = pkg.Scene("scene2")
+    ref = None
+    acc = np.zeros((h, w, 4), dtype=np.float32)
+    for f in range(1, 7):
+        ref = orc.render(s.desc, s.camera(w, h), (), frame_index=f, accumulate=True, seed=0x5EED, accum=acc)
+    a, b = np.load(tmp_path / f"{mode}_0.npy"), np.load(tmp_path / f"{mode}_1.npy")
+    assert np.array_equal(a, b), "the ranks hold different frames after the all-gather"
+    bands = [tuple(np.load(tmp_path / f"{mode}_band_{r}.npy")) for r in range(2)]
+    assert bands[0][0] == 0 and bands[0][1] == bands[1][0] and bands[1][1] == h
+    # the summation order differs from the sequential +=, so bytes may differ by one step at rounding boundaries
+    assert np.abs(a.astype(np.int16) - ref["rgba"].astype(np.int16)).max() <= 1
+    assert (a != ref["rgba"]).mean() < 1e-3
 
 
 def test_sample_shards_cover_every_index_once(pkg):
