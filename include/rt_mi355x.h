@@ -223,6 +223,12 @@ void rt_destroy(rt_ctx *ctx);
  * Scenes with 32 or more bounded objects are traced through a bounding-volume hierarchy (same hits as the linear scan). */
 int32_t rt_set_scene(rt_ctx *ctx, const rt_scene_desc *scene);
 
+/* Re-uploads objects [first, first + count) after the caller changed them, as the binaries' update functions do every
+ * frame (src/bin/scene1.rs:13-24, src/bin/scene4.rs:14-26: mutate position / rotation_axis, then Object3D::update()).
+ * Kinds and Union/Substraction children must be the ones given to rt_set_scene; everything else may change.  Costs
+ * one small copy instead of a scene rebuild (plus a hierarchy rebuild for scenes that use one). */
+int32_t rt_update_objects(rt_ctx *ctx, uint32_t first, uint32_t count, const rt_object *objects);
+
 /* Uploads Scene.textures[index]: tightly packed RGB8, row-major, exactly Texture.bytes
  * (src/objects.rs:105-111) as produced by ImageUtils::load_image (src/utils/image.rs:13-29). */
 int32_t rt_set_texture(rt_ctx *ctx, uint32_t index, uint32_t width, uint32_t height, const uint8_t *rgb8);

@@ -122,7 +122,7 @@ class rt_render_params(C.Structure):
 ABI_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_texture", "rt_set_camera", "rt_render", "rt_render_device",
     "rt_resolve_device", "rt_reset_accum", "rt_read_accum", "rt_get_stats", "rt_context_stream", "rt_device_rgba8", "rt_device_accum", "rt_last_error",
-    "rt_abi_version", "rt_alloc_host_frame", "rt_free_host_frame",
+    "rt_abi_version", "rt_alloc_host_frame", "rt_free_host_frame", "rt_update_objects",
 ]
 
 # RT_MI355X_LIB overrides the library file (used to A/B kernel builds); it is still a HIP build of this backend
@@ -156,6 +156,7 @@ def lib() -> C.CDLL:
         l.rt_resolve_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]; l.rt_resolve_device.restype = C.c_int32
         l.rt_reset_accum.argtypes = [vp]; l.rt_reset_accum.restype = C.c_int32
         l.rt_read_accum.argtypes = [vp, C.c_void_p, C.c_size_t]; l.rt_read_accum.restype = C.c_int32
+        l.rt_update_objects.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(rt_object)]; l.rt_update_objects.restype = C.c_int32
         l.rt_alloc_host_frame.argtypes = [vp, C.c_size_t, C.POINTER(C.c_void_p)]; l.rt_alloc_host_frame.restype = C.c_int32
         l.rt_free_host_frame.argtypes = [vp, C.c_void_p]; l.rt_free_host_frame.restype = C.c_int32
         l.rt_get_stats.argtypes = [vp, C.POINTER(rt_stats)]; l.rt_get_stats.restype = C.c_int32
@@ -189,6 +190,10 @@ def host() -> C.CDLL:
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_char_p, C.c_size_t]
         h.rth_render_frames.restype = C.c_int32
+        h.rth_render_animation.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.POINTER(C.c_uint32),
+                                           C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.POINTER(rt_object),
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+        h.rth_render_animation.restype = C.c_int32
         _host = h
     return _host
 
@@ -311,6 +316,11 @@ class Context:
             raise ValueError("out must be a C-contiguous (height, width, 4) uint8 array")
         self._check(self._l.rt_render(self._ctx, frame_index, int(accumulate), int(reset_accum), seed, out.ctypes.data, out.nbytes), "rt_render")
         return out
+
+    def update_objects(self, first: int, objects) -> None:
+        """rt_update_objects: re-upload the given rt_object records at indices first, first + 1, ..."""
+        arr = (rt_object * len(objects))(*objects)
+        self._check(self._l.rt_update_objects(self._ctx, first, len(objects), arr), "rt_update_objects")
 
     def alloc_host_frame(self) -> np.ndarray:
         """rt_alloc_host_frame: a page-locked (height, width, 4) uint8 array for render(out=...); valid until free_host_frame / close."""

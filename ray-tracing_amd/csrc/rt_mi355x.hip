@@ -59,6 +59,7 @@ struct rt_ctx {
     DevBuf<uint32_t> tex_data[kMaxTextures];
     DevTexture h_textures[kMaxTextures] = {};
     std::vector<int32_t> mat_texture;  // texture index of every material, for the render-time check
+    std::vector<rt_object> h_objects;  // host copy of the scene's objects (rt_update_objects, hierarchy rebuilds)
 
     DevScene scene = {};
     DevCamera camera = {};
@@ -99,6 +100,40 @@ DevXform make_xform(const float *m) {
     return x;
 }
 
+// Device record of one object: matrices as 3-row columns, kind-specific parameters in p[].
+DevObject make_dev_object(const rt_object &o) {
+    DevObject g;
+    std::memset(&g, 0, sizeof(g));
+    g.kind = o.kind;
+    g.material = (o.kind == RT_UNION || o.kind == RT_SUBSTRACTION) ? 0 : o.material_index;
+    g.first = o.first; g.second = o.second;
+    g.inv = make_xform(o.inv_transform);
+    g.fwd = make_xform(o.transform);
+    switch (o.kind) {
+        case RT_SPHERE: g.p[0] = o.radius; break;
+        case RT_CUBOID:
+            for (int k = 0; k < 3; k++) {
+                g.p[k] = o.dimension[k];
+                // b_min / b_max = (Mat4::from_scale(dimension) * vec4(-+1, -+1, -+1, 0)).xyz (src/utils/cuboid.rs:48-49)
+                float col[3] = {0.0f, 0.0f, 0.0f};
+                col[k] = o.dimension[k];
+                g.p[3 + k] = ((col[0] * -1.0f + col[1] * -1.0f) + col[2] * -1.0f) + 0.0f * 0.0f;
+                g.p[6 + k] = ((col[0] * 1.0f + col[1] * 1.0f) + col[2] * 1.0f) + 0.0f * 0.0f;
+            }
+            break;
+        case RT_PLANE:
+            for (int k = 0; k < 3; k++) { g.p[k] = o.normal[k]; g.p[3 + k] = o.point[k]; }
+            g.p[6] = o.max_dist[0]; g.p[7] = o.max_dist[1]; g.p[8] = o.has_max_dist ? 1.0f : 0.0f;
+            break;
+        case RT_CYLINDER: g.p[0] = o.radius; g.p[1] = o.height; break;
+        case RT_TRIANGLE:
+            for (int k = 0; k < 3; k++) { g.p[k] = o.v1[k]; g.p[3 + k] = o.v2[k]; g.p[6 + k] = o.v3[k]; }
+            break;
+        default: break;
+    }
+    return g;
+}
+
 int composite_depth(const rt_scene_desc *d, uint32_t i, int guard) {
     if (i >= d->n_objects || guard > 8) return -1;
     const rt_object &o = d->objects[i];
@@ -135,6 +170,26 @@ hipError_t wait_external(rt_ctx *c, hipStream_t next) {
 template <typename K>
 void launch(K kernel, uint32_t blocks, uint32_t threads, size_t lds, hipStream_t s, const DevScene &S, const DevCamera &C, const DevFrame &F) {
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, s, S, C, F);
+}
+
+// Scenes with many bounded objects get a bounding-volume hierarchy; small scenes keep the reference's linear scan.
+// Built from the context's host copy of the objects (again after rt_update_objects moved some of them).
+int32_t upload_hierarchy(rt_ctx *c) {
+    DevScene &S = c->scene;
+    S.bvh_nodes = nullptr; S.unbounded = nullptr; S.n_bvh_nodes = 0; S.n_unbounded = 0;
+    rt_scene_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.objects = c->h_objects.data(); d.n_objects = (uint32_t)c->h_objects.size();
+    if (S.ray_marching || !rt_bvh_wanted(&d)) return RT_OK;
+    std::vector<DevBvhNode> nodes; std::vector<uint32_t> unbounded;
+    rt_bvh_build(&d, nodes, unbounded);
+    RT_HIP(c, c->bvh_nodes.ensure(nodes.size()));
+    RT_HIP(c, c->unbounded.ensure(unbounded.size() ? unbounded.size() : 1));
+    RT_HIP(c, hipMemcpy(c->bvh_nodes.ptr, nodes.data(), nodes.size() * sizeof(DevBvhNode), hipMemcpyHostToDevice));
+    if (!unbounded.empty()) RT_HIP(c, hipMemcpy(c->unbounded.ptr, unbounded.data(), unbounded.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    S.bvh_nodes = c->bvh_nodes.ptr; S.unbounded = c->unbounded.ptr;
+    S.n_bvh_nodes = (uint32_t)(nodes.size() / kBvhLayouts); S.n_unbounded = (uint32_t)unbounded.size();
+    return RT_OK;
 }
 
 }  // namespace
@@ -215,38 +270,7 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
 
     RT_HIP(c, hipSetDevice(c->device));
     std::vector<DevObject> objs(d->n_objects);
-    for (uint32_t i = 0; i < d->n_objects; i++) {
-        const rt_object &o = d->objects[i];
-        DevObject &g = objs[i];
-        std::memset(&g, 0, sizeof(g));
-        g.kind = o.kind;
-        g.material = (o.kind == RT_UNION || o.kind == RT_SUBSTRACTION) ? 0 : o.material_index;
-        g.first = o.first; g.second = o.second;
-        g.inv = make_xform(o.inv_transform);
-        g.fwd = make_xform(o.transform);
-        switch (o.kind) {
-            case RT_SPHERE: g.p[0] = o.radius; break;
-            case RT_CUBOID:
-                for (int k = 0; k < 3; k++) {
-                    g.p[k] = o.dimension[k];
-                    // b_min / b_max = (Mat4::from_scale(dimension) * vec4(-+1, -+1, -+1, 0)).xyz (src/utils/cuboid.rs:48-49)
-                    float col[3] = {0.0f, 0.0f, 0.0f};
-                    col[k] = o.dimension[k];
-                    g.p[3 + k] = ((col[0] * -1.0f + col[1] * -1.0f) + col[2] * -1.0f) + 0.0f * 0.0f;
-                    g.p[6 + k] = ((col[0] * 1.0f + col[1] * 1.0f) + col[2] * 1.0f) + 0.0f * 0.0f;
-                }
-                break;
-            case RT_PLANE:
-                for (int k = 0; k < 3; k++) { g.p[k] = o.normal[k]; g.p[3 + k] = o.point[k]; }
-                g.p[6] = o.max_dist[0]; g.p[7] = o.max_dist[1]; g.p[8] = o.has_max_dist ? 1.0f : 0.0f;
-                break;
-            case RT_CYLINDER: g.p[0] = o.radius; g.p[1] = o.height; break;
-            case RT_TRIANGLE:
-                for (int k = 0; k < 3; k++) { g.p[k] = o.v1[k]; g.p[3 + k] = o.v2[k]; g.p[6 + k] = o.v3[k]; }
-                break;
-            default: break;
-        }
-    }
+    for (uint32_t i = 0; i < d->n_objects; i++) objs[i] = make_dev_object(d->objects[i]);
     std::vector<DevMaterial> mats(d->n_materials);
     c->mat_texture.assign(d->n_materials, -1);
     c->has_refractive = false;
@@ -288,18 +312,8 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.max_ray_bounces = d->max_ray_bounces; S.shadow_casting = d->shadow_casting; S.ray_marching = d->ray_marching;
     S.diffuse = d->diffuse; S.enable_accumulation = d->enable_accumulation;
 
-    // Scenes with many bounded objects get a bounding-volume hierarchy; small scenes keep the reference's linear scan.
-    S.bvh_nodes = nullptr; S.unbounded = nullptr; S.n_bvh_nodes = 0; S.n_unbounded = 0;
-    if (!d->ray_marching && rt_bvh_wanted(d)) {
-        std::vector<DevBvhNode> nodes; std::vector<uint32_t> unbounded;
-        rt_bvh_build(d, nodes, unbounded);
-        RT_HIP(c, c->bvh_nodes.ensure(nodes.size()));
-        RT_HIP(c, c->unbounded.ensure(unbounded.size() ? unbounded.size() : 1));
-        RT_HIP(c, hipMemcpy(c->bvh_nodes.ptr, nodes.data(), nodes.size() * sizeof(DevBvhNode), hipMemcpyHostToDevice));
-        if (!unbounded.empty()) RT_HIP(c, hipMemcpy(c->unbounded.ptr, unbounded.data(), unbounded.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        S.bvh_nodes = c->bvh_nodes.ptr; S.unbounded = c->unbounded.ptr;
-        S.n_bvh_nodes = (uint32_t)(nodes.size() / kBvhLayouts); S.n_unbounded = (uint32_t)unbounded.size();
-    }
+    c->h_objects.assign(d->objects, d->objects + d->n_objects);
+    { int32_t r = upload_hierarchy(c); if (r != RT_OK) return r; }
     c->leaf_slots = 0;
     if (d->ray_marching) {
         for (uint32_t k = 0; k < d->n_sdfs; k++) {
@@ -309,6 +323,33 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
         }
     }
     c->has_scene = true;
+    return RT_OK;
+}
+
+int32_t rt_update_objects(rt_ctx *c, uint32_t first, uint32_t count, const rt_object *objects) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!c->has_scene) return fail(c, RT_ERR_STATE, "scene not set");
+    if (count == 0) return RT_OK;
+    if (!objects) return fail(c, RT_ERR_INVALID_ARGUMENT, "objects is null");
+    if ((uint64_t)first + count > c->h_objects.size()) return fail(c, RT_ERR_INVALID_ARGUMENT, "object range out of bounds");
+    for (uint32_t i = 0; i < count; i++) {
+        const rt_object &o = objects[i], &old = c->h_objects[first + i];
+        const std::string who = "object " + std::to_string(first + i);
+        if (o.kind != old.kind) return fail(c, RT_ERR_INVALID_ARGUMENT, who + ": kind differs from the scene's (use rt_set_scene)");
+        if (o.kind == RT_UNION || o.kind == RT_SUBSTRACTION) {
+            if (o.first != old.first || o.second != old.second) return fail(c, RT_ERR_INVALID_ARGUMENT, who + ": children differ from the scene's (use rt_set_scene)");
+        } else if (o.material_index < 0 || (uint32_t)o.material_index >= c->scene.n_materials) {
+            return fail(c, RT_ERR_INVALID_ARGUMENT, who + ": material index out of range");
+        }
+    }
+    std::vector<DevObject> objs(count);
+    for (uint32_t i = 0; i < count; i++) objs[i] = make_dev_object(objects[i]);
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, wait_external(c, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpy(c->objects.ptr + first, objs.data(), (size_t)count * sizeof(DevObject), hipMemcpyHostToDevice));
+    std::copy(objects, objects + count, c->h_objects.begin() + first);
+    if (c->scene.bvh_nodes) return upload_hierarchy(c);  // moved objects: new boxes
     return RT_OK;
 }
 

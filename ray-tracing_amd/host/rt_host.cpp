@@ -1,6 +1,7 @@
 // rt_host.cpp — implementation of the host-side mirror declared in rt_host.h.
 #include "rt_host.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -266,6 +267,20 @@ rt_camera_desc Camera::desc() const {
 // ------------------------------------------------------------------------------------------------
 Renderer::~Renderer() { if (ctx_) rt_destroy(ctx_); }
 
+// True when two flattened scenes differ at most in the contents of their object records.
+static bool same_except_object_records(const FlatScene &a, const FlatScene &b) {
+    auto bytes_equal = [](const auto &x, const auto &y) {
+        return x.size() == y.size() && (x.empty() || std::memcmp(x.data(), y.data(), x.size() * sizeof(x[0])) == 0);
+    };
+    if (a.objects.size() != b.objects.size() || !bytes_equal(a.materials, b.materials) || !bytes_equal(a.lights, b.lights) ||
+        !bytes_equal(a.sdfs, b.sdfs))
+        return false;
+    const rt_scene_desc &p = a.desc, &q = b.desc;
+    return p.n_textures == q.n_textures && std::memcmp(p.ambient_color, q.ambient_color, sizeof(p.ambient_color)) == 0 &&
+           p.max_ray_bounces == q.max_ray_bounces && p.shadow_casting == q.shadow_casting && p.ray_marching == q.ray_marching &&
+           p.diffuse == q.diffuse && p.enable_accumulation == q.enable_accumulation;
+}
+
 std::string Renderer::render(Scene &scene, std::vector<uint8_t> &img, const Camera &camera, bool updated, size_t /*num_chunks*/) {
     auto fail = [&](const char *what) { return std::string(what) + ": " + (ctx_ ? rt_last_error(ctx_) : "no context"); };
     if (!ctx_) {
@@ -282,8 +297,29 @@ std::string Renderer::render(Scene &scene, std::vector<uint8_t> &img, const Came
             if (rt_set_texture(ctx_, (uint32_t)i, t.width, t.height, t.bytes.data()) != RT_OK) return fail("rt_set_texture");
             uploaded_textures_ = i + 1;
         }
+        // The binaries' update functions (src/bin/scene1.rs:13-24, scene4.rs:14-26) move a few objects per frame:
+        // when only object records changed (same kinds, same composite children), send just that range.
         FlatScene flat; flatten(scene, flat);
-        if (rt_set_scene(ctx_, &flat.desc) != RT_OK) return fail("rt_set_scene");
+        size_t lo = flat.objects.size(), hi = 0;
+        bool same_shape = scene_uploaded_ && same_except_object_records(last_, flat);
+        if (same_shape) {
+            for (size_t i = 0; i < flat.objects.size(); i++) {
+                if (std::memcmp(&flat.objects[i], &last_.objects[i], sizeof(rt_object)) == 0) continue;
+                const rt_object &a = flat.objects[i], &b = last_.objects[i];
+                if (a.kind != b.kind || a.first != b.first || a.second != b.second) { same_shape = false; break; }
+                lo = std::min(lo, i); hi = std::max(hi, i + 1);
+            }
+        }
+        if (!same_shape) {
+            if (rt_set_scene(ctx_, &flat.desc) != RT_OK) return fail("rt_set_scene");
+            full_uploads_ += 1;
+        } else if (lo < hi) {
+            if (rt_update_objects(ctx_, (uint32_t)lo, (uint32_t)(hi - lo), flat.objects.data() + lo) != RT_OK) return fail("rt_update_objects");
+            object_updates_ += 1;
+        }
+        last_ = std::move(flat);
+        last_.desc.objects = last_.objects.data(); last_.desc.materials = last_.materials.data();
+        last_.desc.lights = last_.lights.data(); last_.desc.sdfs = last_.sdfs.data();
         rt_camera_desc cd = camera.desc();
         if (rt_set_camera(ctx_, &cd) != RT_OK) return fail("rt_set_camera");
         scene_uploaded_ = true;
@@ -337,6 +373,44 @@ void rth_camera(const float position[3], const float look_at[3], uint32_t width,
     *out = c.desc();
 }
 void rth_object_update(rt_object *o) { rt::Object3D x; x.o = *o; x.update(); *o = x.o; }
+
+// App3D::run's frame loop without the window (src/app.rs:219-248): every frame calls the scene's update function with
+// ts = frame * dt, then Renderer::render with its return value as `updated`.  Writes the n_frames RGBA8 frames back to
+// back into img_out and, per frame, the flattened objects after the update into objects_out (n_frames * n_objects).
+int32_t rth_render_animation(rth_scene *s, uint32_t width, uint32_t height, uint32_t n_frames, float dt, uint32_t n_textures,
+                             const uint32_t *tex_w, const uint32_t *tex_h, const uint8_t *const *tex_rgb8, int32_t device_id,
+                             uint8_t *img_out, rt_object *objects_out, uint64_t *full_uploads, uint64_t *object_updates,
+                             char *err, size_t err_len) {
+    auto fail = [&](const std::string &m) { if (err && err_len) { std::strncpy(err, m.c_str(), err_len - 1); err[err_len - 1] = 0; } return -1; };
+    if (!s || !img_out) return fail("null argument");
+    rt::Scene scene = s->built.scene;
+    scene.textures.clear();
+    for (uint32_t i = 0; i < n_textures; i++) {
+        rt::Texture t; t.width = tex_w[i]; t.height = tex_h[i];
+        t.bytes.assign(tex_rgb8[i], tex_rgb8[i] + (size_t)tex_w[i] * tex_h[i] * 3);
+        scene = scene.with_texture(t);
+    }
+    rt::Camera camera = s->built.camera;
+    rt::CameraEvent e; e.kind = rt::CameraEvent::Resize; e.w = width; e.h = height;
+    camera.update({e}, 0.0f);
+    rt::Renderer renderer; renderer.device_id = device_id;
+    const size_t frame_bytes = (size_t)width * height * 4;
+    std::vector<uint8_t> img(frame_bytes, 0);
+    for (uint32_t f = 0; f < n_frames; f++) {
+        bool updated = f == 0;
+        if (scene.update_func && scene.update_func(scene, (float)f * dt)) updated = true;
+        std::string r = renderer.render(scene, img, camera, updated, 200);
+        if (!r.empty()) return fail(r);
+        std::memcpy(img_out + (size_t)f * frame_bytes, img.data(), frame_bytes);
+        if (objects_out) {
+            rt::FlatScene flat; rt::flatten(scene, flat);
+            std::memcpy(objects_out + (size_t)f * flat.objects.size(), flat.objects.data(), flat.objects.size() * sizeof(rt_object));
+        }
+    }
+    if (full_uploads) *full_uploads = renderer.full_uploads();
+    if (object_updates) *object_updates = renderer.object_updates();
+    return 0;
+}
 
 int32_t rth_render_frames(rth_scene *s, uint32_t width, uint32_t height, uint32_t n_frames, int32_t accumulate, uint32_t n_textures,
                           const uint32_t *tex_w, const uint32_t *tex_h, const uint8_t *const *tex_rgb8, int32_t device_id,

@@ -187,6 +187,12 @@ struct Renderer {
     rt_ctx *ctx_ = nullptr;
     size_t uploaded_textures_ = 0;
     bool scene_uploaded_ = false;
+    FlatScene last_;           // what the device holds: an `updated` frame re-uploads only the objects that moved
+    uint64_t full_uploads_ = 0, object_updates_ = 0;
+
+  public:
+    uint64_t full_uploads() const { return full_uploads_; }      // rt_set_scene calls so far
+    uint64_t object_updates() const { return object_updates_; }  // rt_update_objects calls so far
 };
 
 // The reference's demo scenes as data (src/bin/scene1.rs .. scene4.rs, construction-time state) and the
@@ -223,4 +229,11 @@ void rth_object_update(rt_object *o);
 int32_t rth_render_frames(rth_scene *s, uint32_t width, uint32_t height, uint32_t n_frames, int32_t accumulate,
                           uint32_t n_textures, const uint32_t *tex_w, const uint32_t *tex_h, const uint8_t *const *tex_rgb8,
                           int32_t device_id, uint8_t *img_out, float *accum_out, char *err, size_t err_len);
+// App3D::run's frame loop without the window (src/app.rs:219-248): per frame the scene's update function (ts = frame * dt),
+// then Renderer::render.  img_out receives n_frames frames back to back, objects_out (may be NULL) the flattened objects
+// after each update (n_frames * n_objects); the two counters report how the scene reached the device.
+int32_t rth_render_animation(rth_scene *s, uint32_t width, uint32_t height, uint32_t n_frames, float dt, uint32_t n_textures,
+                             const uint32_t *tex_w, const uint32_t *tex_h, const uint8_t *const *tex_rgb8, int32_t device_id,
+                             uint8_t *img_out, rt_object *objects_out, uint64_t *full_uploads, uint64_t *object_updates,
+                             char *err, size_t err_len);
 }

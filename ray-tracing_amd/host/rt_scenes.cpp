@@ -1,7 +1,7 @@
 // rt_scenes.cpp — the reference's four demo scenes and two synthetic benchmark scenes, as data.
 //
-// Each builder restates the literals of one reference binary at construction time (no update_func
-// tick applied):  scene1 src/bin/scene1.rs:27-175, scene2 src/bin/scene2.rs:24-62,
+// Each builder restates the literals of one reference binary at construction time, and sets
+// Scene::update_func to the binary's per-frame update (applied only by callers that animate):  scene1 src/bin/scene1.rs:27-175, scene2 src/bin/scene2.rs:24-62,
 // scene3 src/bin/scene3.rs:20-73, scene4 src/bin/scene4.rs:29-118.
 // tex4 and spheres10k have no counterpart in the reference; they exercise texture sampling on all four
 // shipped images and a 10 000-object scene respectively.
@@ -22,6 +22,47 @@ static Material mat(float ambience, float diffuse, float shininess, float specul
 static void declare_texture_slots(Scene &s, size_t n) {
     static const char *names[4] = {"chess.png", "wood.png", "stone3.jpg", "earth_clouds.jpg"};
     for (size_t i = 0; i < n; i++) { Texture t; t.path = names[i % 4]; s.textures.push_back(t); }
+}
+
+// src/bin/scene1.rs:13-24: the cuboid (object 3) tumbles
+static bool update_scene1(Scene &s, float /*ts*/) {
+    const float speed = 0.2f;
+    if (s.objects.size() > 3 && s.objects[3].o.kind == RT_CUBOID) {
+        rt_object &c = s.objects[3].o;
+        c.rotation_axis[0] += 2.0f * speed;
+        c.rotation_axis[2] += 4.0f * speed;
+        c.rotation_axis[1] += 2.0f * speed;
+        s.objects[3].update();
+    }
+    return true;
+}
+// src/bin/scene2.rs:9-21: the first cuboid tumbles
+static bool update_scene2(Scene &s, float /*ts*/) {
+    const float speed = 0.2f;
+    for (Object3D &obj : s.objects) {
+        if (obj.o.kind != RT_CUBOID) continue;
+        obj.o.rotation_axis[0] += 2.0f * speed;
+        obj.o.rotation_axis[2] += 4.0f * speed;
+        obj.o.rotation_axis[1] += 2.0f * speed;
+        obj.update();
+        break;
+    }
+    return true;
+}
+// src/bin/scene3.rs:10-12
+static bool update_scene3(Scene &, float) { return false; }
+// src/bin/scene4.rs:14-26: the sphere (object 2) bobs, the cylinder (object 3) spins
+static bool update_scene4(Scene &s, float ts) {
+    const float speed = 0.5f;
+    if (s.objects.size() > 2 && s.objects[2].o.kind == RT_SPHERE) {
+        s.objects[2].o.position[1] = std::sin(ts) * 2.0f * speed + 0.8f;
+        s.objects[2].update();
+    }
+    if (s.objects.size() > 3 && s.objects[3].o.kind == RT_CYLINDER) {
+        s.objects[3].o.rotation_axis[1] += 2.0f * speed;
+        s.objects[3].update();
+    }
+    return true;
 }
 
 Built scene1() {
@@ -197,10 +238,10 @@ Built spheres10k(uint32_t n_spheres, uint64_t seed) {
 }
 
 bool by_name(const std::string &name, Built &out) {
-    if (name == "scene1") { out = scene1(); return true; }
-    if (name == "scene2") { out = scene2(); return true; }
-    if (name == "scene3") { out = scene3(); return true; }
-    if (name == "scene4") { out = scene4(); return true; }
+    if (name == "scene1") { out = scene1(); out.scene.update_func = update_scene1; return true; }
+    if (name == "scene2") { out = scene2(); out.scene.update_func = update_scene2; return true; }
+    if (name == "scene3") { out = scene3(); out.scene.update_func = update_scene3; return true; }
+    if (name == "scene4") { out = scene4(); out.scene.update_func = update_scene4; return true; }
     if (name == "tex4") { out = tex4(); return true; }
     if (name == "spheres10k") { out = spheres10k(); return true; }
     if (name == "spheres1k") { out = spheres10k(1000); return true; }

@@ -317,6 +317,74 @@ def test_renderer_mirror_follows_renderer_rs(pkg, orc):
     assert_parity(img, ref["rgba"], acc, ref["accum"], what="Renderer scene1")
 
 
+def _scene_with_objects(pkg, s, objs):
+    """A scene description equal to s.desc except for its object records."""
+    d = s.desc
+    return SceneBuilder(pkg, objs, [d.materials[i] for i in range(d.n_materials)], [d.lights[i] for i in range(d.n_lights)],
+                        sdfs=[d.sdfs[i] for i in range(d.n_sdfs)], n_textures=d.n_textures, ray_marching=d.ray_marching,
+                        max_ray_bounces=d.max_ray_bounces, shadow_casting=d.shadow_casting, diffuse=d.diffuse,
+                        ambient_color=tuple(d.ambient_color), enable_accumulation=d.enable_accumulation)
+
+
+@pytest.mark.parametrize("name", ["scene1", "scene4", "spheres200"])
+def test_update_objects_equals_a_fresh_scene(pkg, orc, ctx, name):
+    """rt_update_objects after moving objects (what the binaries' update functions do) == oracle on the moved scene."""
+    s = pkg.Scene(name)
+    w, h = 160, 120
+    ctx.load(s, w, h)
+    n = s.desc.n_objects
+    objs = [pkg.rt_object.from_buffer_copy(s.desc.objects[i]) for i in range(n)]
+    movable = [i for i in range(n) if objs[i].kind in (pkg.RT_SPHERE, pkg.RT_CUBOID, pkg.RT_CYLINDER)]
+    first = movable[1] if len(movable) > 1 else movable[0]
+    chosen = [i for i in movable if first <= i < first + 12]
+    for step in (1, 2):
+        for i in chosen:
+            objs[i].position[1] += 0.15 * step
+            objs[i].rotation_axis[1] += 20.0
+            pkg.host().rth_object_update(C.byref(objs[i]))
+        lo, hi = min(chosen), max(chosen) + 1
+        ctx.update_objects(lo, objs[lo:hi])
+        sb = _scene_with_objects(pkg, s, objs)
+        rgba, lin, st = gpu_frame(ctx, accumulate=bool(s.desc.diffuse), seed=11, events=True)
+        ref = orc.render(sb.desc, s.camera(w, h), s.textures(), accumulate=bool(s.desc.diffuse), seed=11, want_counters=True, n_threads=8)
+        assert_parity(rgba, ref["rgba"], lin, ref["accum"], what=f"{name} after update {step}")
+        cref = dict(zip(pkg.COUNTER_NAMES, ref["counters"]))
+        assert _counters_without_candidate_tests(pkg, st) == _counters_without_candidate_tests(pkg, cref)
+    l = pkg.lib()
+    bad = pkg.rt_object.from_buffer_copy(objs[first]); bad.kind = pkg.RT_TRIANGLE
+    assert l.rt_update_objects(ctx._ctx, first, 1, C.byref(bad)) == -1 and b"kind differs" in l.rt_last_error(ctx._ctx)
+    assert l.rt_update_objects(ctx._ctx, n, 1, C.byref(objs[0])) == -1 and b"out of bounds" in l.rt_last_error(ctx._ctx)
+    bad = pkg.rt_object.from_buffer_copy(objs[first]); bad.material_index = 10 ** 6
+    assert l.rt_update_objects(ctx._ctx, first, 1, C.byref(bad)) == -1 and b"material index" in l.rt_last_error(ctx._ctx)
+    assert l.rt_update_objects(ctx._ctx, 0, 0, None) == 0
+
+
+@pytest.mark.parametrize("name", ["scene1", "scene4"])
+def test_animated_scene_through_the_renderer_mirror(pkg, orc, name):
+    """App3D::run's loop (update function, then Renderer::render) for four frames: every frame equals the oracle on that
+    frame's objects, and after the first frame only the moved objects are re-uploaded."""
+    h = pkg.host()
+    s = pkg.Scene(name)
+    w, hh, frames = 128, 96, 4
+    n = s.desc.n_objects
+    tex = s.textures()
+    tw = (C.c_uint32 * 4)(*[t.shape[1] for t in tex])
+    th = (C.c_uint32 * 4)(*[t.shape[0] for t in tex])
+    tp = (C.c_void_p * 4)(*[t.ctypes.data for t in tex])
+    img = np.zeros((frames, hh, w, 4), dtype=np.uint8)
+    objs = (pkg.rt_object * (frames * n))()
+    full, part = C.c_uint64(), C.c_uint64()
+    err = C.create_string_buffer(256)
+    st = h.rth_render_animation(s.handle(), w, hh, frames, 0.25, 4, tw, th, tp, 0, img.ctypes.data, objs, C.byref(full), C.byref(part), err, 256)
+    assert st == 0, err.value
+    assert (full.value, part.value) == (1, frames - 1)
+    for f in range(frames):
+        sb = _scene_with_objects(pkg, s, [objs[f * n + i] for i in range(n)])
+        ref = orc.render(sb.desc, s.camera(w, hh), tex, n_threads=8)
+        assert np.array_equal(img[f], ref["rgba"]), f"{name} frame {f}"
+    assert not np.array_equal(img[0], img[frames - 1]), "the animation did not move anything"
+
+
 @pytest.mark.parametrize("name", ["scene3", "scene1", "tex4", "scene4"])
 def test_full_size_4k_properties(pkg, orc, ctx, name):
     """3840x2160 (the benchmark size): determinism, variant agreement, and oracle parity on sampled rows."""
