@@ -228,9 +228,15 @@ def cpu_baseline(pkg, scene, width, height, accumulate) -> dict:
     rays = 0
     t0 = time.perf_counter()
     if starts is None:
-        r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, want_counters=True)
-        rays = sum(r["counters"][:5])
-        sample = f"1 full {width}x{height} frame"
+        # cheap scenes: whole frames, repeated until the cores have worked for about 20 core-seconds
+        orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads)   # warm-up (page faults, thread start)
+        t0 = time.perf_counter()
+        frames = 0
+        while frames < 3 or (time.perf_counter() - t0) * threads < 20.0:
+            r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, want_counters=True)
+            rays += sum(r["counters"][:5])
+            frames += 1
+        sample = f"{frames} full {width}x{height} frames"
     else:
         for y in sorted(set(starts)):
             r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, want_counters=True, rows=(y, y + 8))
