@@ -58,11 +58,19 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU; RT_BENCH_BACKEND=gloo rehearses the multi-process launch of the default (frames) sharding on a
+    # box with fewer GPUs than ranks (ranks then share devices round-robin; gloo's collectives on device tensors are
+    # not what the rows / samples modes are written for)
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
+    torch.cuda.set_device(device_index)
 
     pkg = graft.load_package()
     scene_name, width, height, bounces, accumulate, spp, default_shard, description = WORKLOADS[args.workload]
@@ -70,7 +78,7 @@ def main() -> None:
     scene = pkg.Scene(scene_name)
     if bounces is not None:
         scene.desc.max_ray_bounces = bounces
-    ctx = pkg.Context(local_rank)
+    ctx = pkg.Context(device_index)
     ctx.load(scene, width, height)
 
     rgba = torch.zeros((height, width, 4), dtype=torch.uint8, device="cuda")
@@ -114,7 +122,7 @@ def main() -> None:
             else:
                 # the band is its own tensor: resolve it as rows [0, re - rb) straight into this rank's rows of the frame
                 ctx.resolve_device(spp, rows=(0, re - rb), d_accum=band.data_ptr(), d_rgba8=rgba.data_ptr() + rb * width * 4, stream=sh)
-                pkg.gather_equal_bands(dist, rgba[rb:re], rgba)
+                pkg.gather_equal_bands(dist, rgba[rb:re].clone(), rgba)   # the send buffer must not alias the receive buffer
 
     def rays_of_step(i: int) -> int:
         """Rays this rank traces in step i (untimed pass: one stats read-back per render)."""
