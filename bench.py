@@ -229,6 +229,8 @@ def cpu_baseline(pkg, scene, width, height, accumulate) -> dict:
     threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
     cam = scene.camera(width, height)
     tex = scene.textures()
+    # Camera.ray_directions is computed once per camera change in the reference (src/camera.rs:128-157), outside the frames
+    dirs = orc.ray_directions(cam)
     # bounded sample: evenly spaced 8-row bands covering ~1/6 of the frame (all of it for cheap scenes), about 10-30 s of core time
     budget_rows = height if not scene.desc.ray_marching and scene.desc.n_objects < 100 else max(8, height // 48)
     n_bands = max(1, budget_rows // 8)
@@ -237,17 +239,17 @@ def cpu_baseline(pkg, scene, width, height, accumulate) -> dict:
     t0 = time.perf_counter()
     if starts is None:
         # cheap scenes: whole frames, repeated until the cores have worked for about 20 core-seconds
-        orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads)   # warm-up (page faults, thread start)
+        orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, ray_dirs=dirs)   # warm-up (page faults, thread start)
         t0 = time.perf_counter()
         frames = 0
         while frames < 3 or (time.perf_counter() - t0) * threads < 20.0:
-            r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, want_counters=True)
+            r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, want_counters=True, ray_dirs=dirs)
             rays += sum(r["counters"][:5])
             frames += 1
         sample = f"{frames} full {width}x{height} frames"
     else:
         for y in sorted(set(starts)):
-            r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, want_counters=True, rows=(y, y + 8))
+            r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, want_counters=True, rows=(y, y + 8), ray_dirs=dirs)
             rays += sum(r["counters"][:5])
         sample = f"{len(set(starts))} evenly spaced 8-row bands of the {width}x{height} frame"
     dt = time.perf_counter() - t0

@@ -233,8 +233,8 @@ int32_t rt_update_objects(rt_ctx *ctx, uint32_t first, uint32_t count, const rt_
  * (src/objects.rs:105-111) as produced by ImageUtils::load_image (src/utils/image.rs:13-29). */
 int32_t rt_set_texture(rt_ctx *ctx, uint32_t index, uint32_t width, uint32_t height, const uint8_t *rgb8);
 
-/* Replaces Camera::calculate_ray_directions (src/camera.rs:128-157): the kernels generate the
- * primary direction of each pixel from these matrices instead of reading a w*h table. */
+/* Camera::update's tail (src/camera.rs:117-124): stores the matrices and runs Camera::calculate_ray_directions
+ * (src/camera.rs:128-157) on the device, once per camera change as in the reference. */
 int32_t rt_set_camera(rt_ctx *ctx, const rt_camera_desc *camera);
 
 /* Renderer::render's pixel work (src/renderer.rs:104-143) for one frame into a host buffer:
@@ -269,6 +269,10 @@ int32_t rt_reset_accum(rt_ctx *ctx);
 
 /* Copies Renderer.accumulated (src/renderer.rs:14) back: n = width*height float4 values. */
 int32_t rt_read_accum(rt_ctx *ctx, float *out_vec4, size_t n_vec4);
+
+/* Copies Camera.ray_directions (src/camera.rs:16) back: n = width*height directions of 3 floats, row-major.  rt_set_camera
+ * fills the device table (Camera::calculate_ray_directions, src/camera.rs:128-157); frames only read it. */
+int32_t rt_read_ray_directions(rt_ctx *ctx, float *out_vec3, size_t n_vec3);
 
 /* Waits for the context's stream and sums the per-workgroup counters of the last render. */
 int32_t rt_get_stats(rt_ctx *ctx, rt_stats *out);

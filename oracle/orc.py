@@ -30,6 +30,9 @@ def load(host_libm: bool = False) -> C.CDLL:
         vp = C.c_void_p
         l.orc_render.argtypes = [vp, vp, vp, C.c_uint32, C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_int32]
         l.orc_render.restype = C.c_int32
+        l.orc_render_with_directions.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_int32]
+        l.orc_render_with_directions.restype = C.c_int32
+        l.orc_ray_directions.argtypes = [vp, vp]; l.orc_ray_directions.restype = None
         l.orc_camera_ray.argtypes = [vp, C.c_uint32, C.c_uint32, vp]; l.orc_camera_ray.restype = None
         l.orc_camera_matrices.argtypes = [vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
         l.orc_camera_matrices.restype = None
@@ -64,8 +67,15 @@ def texture_array(textures, n_slots=0):
     return arr, keep
 
 
+def ray_directions(camera, host_libm=False):
+    """Camera::calculate_ray_directions: the (h, w, 3) f32 table of primary directions."""
+    out = np.zeros((camera.height, camera.width, 3), dtype=np.float32)
+    load(host_libm).orc_ray_directions(C.addressof(camera), out.ctypes.data)
+    return out
+
+
 def render(desc, camera, textures=(), frame_index=1, accumulate=False, seed=0x5EED, rows=None, accum=None, n_threads=1,
-           want_linear=False, want_counters=False, host_libm=False):
+           want_linear=False, want_counters=False, host_libm=False, ray_dirs=None):
     """One frame of the reference algorithm on the CPU.
 
     Returns dict(rgba=(h,w,4) u8, accum=(h,w,4) f32, linear=(h,w,4) f32 or None, counters=list or None).
@@ -80,9 +90,12 @@ def render(desc, camera, textures=(), frame_index=1, accumulate=False, seed=0x5E
     counters = (C.c_uint64 * 64)() if want_counters else None
     tex, keep = texture_array(list(textures), int(desc.n_textures))
     rb, re = rows if rows is not None else (0, 0)
-    st = l.orc_render(C.addressof(desc), C.addressof(tex), C.addressof(camera), frame_index, int(accumulate), seed, rb, re,
-                      accum.ctypes.data, rgba.ctypes.data, linear.ctypes.data if want_linear else None,
-                      C.addressof(counters) if want_counters else None, n_threads)
+    if ray_dirs is not None and (ray_dirs.dtype != np.float32 or ray_dirs.shape != (h, w, 3) or not ray_dirs.flags.c_contiguous):
+        raise ValueError("ray_dirs must be the (h, w, 3) float32 table of ray_directions()")
+    st = l.orc_render_with_directions(C.addressof(desc), C.addressof(tex), C.addressof(camera),
+                                      ray_dirs.ctypes.data if ray_dirs is not None else None, frame_index, int(accumulate), seed, rb, re,
+                                      accum.ctypes.data, rgba.ctypes.data, linear.ctypes.data if want_linear else None,
+                                      C.addressof(counters) if want_counters else None, n_threads)
     if st != 0:
         raise ValueError("orc_render rejected the scene (index out of range / missing texture)")
     return dict(rgba=rgba, accum=accum, linear=linear, counters=list(counters) if want_counters else None)

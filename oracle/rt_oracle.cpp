@@ -790,13 +790,15 @@ static void to_rgba(Vec4 c, uint8_t *out) {
 }
 
 // src/renderer.rs:38-79  render_chunk over pixels [p0, p1)
-static void render_chunk(const Scene &scene, const rt_camera_desc &cam, uint32_t frame_index, bool accumulate, uint64_t seed,
+// ray_dirs: Camera.ray_directions (src/camera.rs:16), the table calculate_ray_directions fills on every camera change and
+// render_chunk reads (src/renderer.rs:49); null = compute the same value on the spot.
+static void render_chunk(const Scene &scene, const rt_camera_desc &cam, const float *ray_dirs, uint32_t frame_index, bool accumulate, uint64_t seed,
                          size_t p0, size_t p1, float *accum, uint8_t *rgba, float *linear, Counters *cnt) {
     Vec3 position = ld3(cam.position);
     for (size_t pos = p0; pos < p1; pos++) {
         uint32_t x = (uint32_t)(pos % cam.width), y = (uint32_t)(pos / cam.width);
         if (cnt) { cnt->c[RT_CNT_RAYGEN]++; cnt->c[RT_CNT_PIXEL_PACK]++; }
-        Vec3 ray_dir = camera_ray_dir(cam, x, y);
+        Vec3 ray_dir = ray_dirs ? ld3(ray_dirs + 3 * pos) : camera_ray_dir(cam, x, y);
         uint32_t key = rng_path_key(seed, (uint32_t)pos, frame_index);
         Vec4 p = scene_pixel(scene, Ray{position, ray_dir}, key, cnt);
         if (linear) { linear[4 * pos] = p.x; linear[4 * pos + 1] = p.y; linear[4 * pos + 2] = p.z; linear[4 * pos + 3] = p.w; }
@@ -823,6 +825,24 @@ extern "C" {
 int32_t orc_render(const rt_scene_desc *sd, const orc_texture *textures, const rt_camera_desc *camera, uint32_t frame_index,
                    int32_t accumulate, uint64_t seed, uint32_t row_begin, uint32_t row_end, float *accum, uint8_t *rgba,
                    float *linear, uint64_t *counters, int32_t n_threads) {
+    return orc_render_with_directions(sd, textures, camera, nullptr, frame_index, accumulate, seed, row_begin, row_end, accum, rgba,
+                                      linear, counters, n_threads);
+}
+
+// src/camera.rs:128-157: the whole table, row-major, 3 floats per pixel
+void orc_ray_directions(const rt_camera_desc *camera, float *out) {
+    for (uint32_t y = 0; y < camera->height; y++)
+        for (uint32_t x = 0; x < camera->width; x++) {
+            Vec3 d = camera_ray_dir(*camera, x, y);
+            float *o = out + 3 * ((size_t)x + (size_t)y * camera->width);
+            o[0] = d.x; o[1] = d.y; o[2] = d.z;
+        }
+}
+
+int32_t orc_render_with_directions(const rt_scene_desc *sd, const orc_texture *textures, const rt_camera_desc *camera,
+                                   const float *ray_dirs, uint32_t frame_index, int32_t accumulate, uint64_t seed,
+                                   uint32_t row_begin, uint32_t row_end, float *accum, uint8_t *rgba, float *linear,
+                                   uint64_t *counters, int32_t n_threads) {
     Scene scene;
     if (!camera || !accum || !rgba || camera->width == 0 || camera->height == 0) return -1;
     if (!load_scene(sd, textures, scene)) return -1;
@@ -844,7 +864,7 @@ int32_t orc_render(const rt_scene_desc *sd, const orc_texture *textures, const r
             if (ci >= n_chunks) break;
             size_t p0 = first + ci * chunk, p1 = p0 + chunk;
             if (p1 > last) p1 = last;
-            render_chunk(scene, *camera, frame_index, accumulate != 0, seed, p0, p1, accum, rgba, linear,
+            render_chunk(scene, *camera, ray_dirs, frame_index, accumulate != 0, seed, p0, p1, accum, rgba, linear,
                          counters ? &cnts[(size_t)tid] : nullptr);
         }
     };

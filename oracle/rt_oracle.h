@@ -35,6 +35,16 @@ int32_t orc_render(const rt_scene_desc *scene, const orc_texture *textures, cons
                    uint32_t frame_index, int32_t accumulate, uint64_t seed, uint32_t row_begin, uint32_t row_end,
                    float *accum, uint8_t *rgba, float *linear, uint64_t *counters, int32_t n_threads);
 
+/* The same frame with Camera.ray_directions supplied (the reference computes that table once per camera change,
+ * src/camera.rs:128-157, and render_chunk only reads it, src/renderer.rs:49); ray_dirs = width*height*3 floats. */
+int32_t orc_render_with_directions(const rt_scene_desc *scene, const orc_texture *textures, const rt_camera_desc *camera,
+                                   const float *ray_dirs, uint32_t frame_index, int32_t accumulate, uint64_t seed,
+                                   uint32_t row_begin, uint32_t row_end, float *accum, uint8_t *rgba, float *linear,
+                                   uint64_t *counters, int32_t n_threads);
+
+/* Camera::calculate_ray_directions (src/camera.rs:128-157): out = width*height*3 floats, row-major. */
+void orc_ray_directions(const rt_camera_desc *camera, float *out);
+
 /* Camera::calculate_ray_directions for one pixel (src/camera.rs:137-148). */
 void orc_camera_ray(const rt_camera_desc *camera, uint32_t x, uint32_t y, float dir[3]);
 

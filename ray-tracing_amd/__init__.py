@@ -44,7 +44,10 @@ RT_CNT_COUNT = len(COUNTER_NAMES)
 # Algorithmic FLOPs per counted event: the reference's own arithmetic, 1 per add/mul/div/sqrt/min/max/
 # transcendental, minimal 3x3(+t) form for matrix-vector products (direction 15, point 18).
 EVENT_FLOPS = {
-    "raygen": 65,
+    # "raygen" counts the pixels whose primary direction a frame reads from Camera.ray_directions (src/renderer.rs:49).
+    # The 65 FLOPs of computing one direction (src/camera.rs:137-148) are spent once per camera change, by the reference
+    # and by rt_set_camera alike, so they are not part of a frame's algorithmic work.
+    "raygen": 0,
     "test_sphere": 54, "hit_sphere": 51,
     "test_plane": 14, "hit_plane": 16,
     "test_cuboid": 58, "hit_cuboid": 61,
@@ -122,7 +125,7 @@ class rt_render_params(C.Structure):
 ABI_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_texture", "rt_set_camera", "rt_render", "rt_render_device",
     "rt_resolve_device", "rt_reset_accum", "rt_read_accum", "rt_get_stats", "rt_context_stream", "rt_device_rgba8", "rt_device_accum", "rt_last_error",
-    "rt_abi_version", "rt_alloc_host_frame", "rt_free_host_frame", "rt_update_objects",
+    "rt_abi_version", "rt_alloc_host_frame", "rt_free_host_frame", "rt_update_objects", "rt_read_ray_directions",
 ]
 
 # RT_MI355X_LIB overrides the library file (used to A/B kernel builds); it is still a HIP build of this backend
@@ -157,6 +160,7 @@ def lib() -> C.CDLL:
         l.rt_reset_accum.argtypes = [vp]; l.rt_reset_accum.restype = C.c_int32
         l.rt_read_accum.argtypes = [vp, C.c_void_p, C.c_size_t]; l.rt_read_accum.restype = C.c_int32
         l.rt_update_objects.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(rt_object)]; l.rt_update_objects.restype = C.c_int32
+        l.rt_read_ray_directions.argtypes = [vp, C.c_void_p, C.c_size_t]; l.rt_read_ray_directions.restype = C.c_int32
         l.rt_alloc_host_frame.argtypes = [vp, C.c_size_t, C.POINTER(C.c_void_p)]; l.rt_alloc_host_frame.restype = C.c_int32
         l.rt_free_host_frame.argtypes = [vp, C.c_void_p]; l.rt_free_host_frame.restype = C.c_int32
         l.rt_get_stats.argtypes = [vp, C.POINTER(rt_stats)]; l.rt_get_stats.restype = C.c_int32
@@ -321,6 +325,12 @@ class Context:
         """rt_update_objects: re-upload the given rt_object records at indices first, first + 1, ..."""
         arr = (rt_object * len(objects))(*objects)
         self._check(self._l.rt_update_objects(self._ctx, first, len(objects), arr), "rt_update_objects")
+
+    def read_ray_directions(self) -> np.ndarray:
+        """rt_read_ray_directions: Camera.ray_directions as an (h, w, 3) float32 array."""
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        self._check(self._l.rt_read_ray_directions(self._ctx, out.ctypes.data, self.width * self.height), "rt_read_ray_directions")
+        return out
 
     def alloc_host_frame(self) -> np.ndarray:
         """rt_alloc_host_frame: a page-locked (height, width, 4) uint8 array for render(out=...); valid until free_host_frame / close."""

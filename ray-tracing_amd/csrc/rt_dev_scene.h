@@ -83,6 +83,7 @@ struct DevCamera {
     float position[3];
     uint32_t width, height;
     float inv_w, inv_h;  // 1 / width as f32, 1 / height as f32 (src/camera.rs:132-133)
+    const float *ray_dirs;  // Camera.ray_directions (src/camera.rs:16): width*height*3 floats, filled by rt_raygen_kernel at rt_set_camera
 };
 
 struct DevFrame {

@@ -568,6 +568,9 @@ RT_DEV void store_pixel(const DevFrame &F, uint32_t pos, f3 p) {
     F.rgba[pos] = r | (g << 8) | (b << 16) | (a8 << 24);
 }
 
+// The workgroup's row in the counter table (2-D grid, see lane_pixel).
+RT_DEV uint32_t rt_block_index() { return blockIdx.y * gridDim.x + blockIdx.x; }
+
 // Sums the per-lane counters of a workgroup and writes one row of F.counters.
 template <bool EVENTS>
 RT_DEV void flush_counters(const DevFrame &F, Cnt<EVENTS> &cnt, uint32_t *s_cnt) {
@@ -585,21 +588,19 @@ RT_DEV void flush_counters(const DevFrame &F, Cnt<EVENTS> &cnt, uint32_t *s_cnt)
         if (lane == 0u && v != 0u) atomicAdd(&s_cnt[i], v);
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < (uint32_t)N; i += blockDim.x) F.counters[blockIdx.x * (uint32_t)N + i] = s_cnt[i];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)N; i += blockDim.x) F.counters[rt_block_index() * (uint32_t)N + i] = s_cnt[i];
 }
 
-// pixel of this lane: wavefronts enumerate 8x8 tiles row-major over the rendered rows
+// pixel of this lane: a wavefront owns one 8x8 tile; blockIdx.y is the tile row, blockIdx.x * waves + wave the tile column
+// (a 2-D grid: no integer division).
 RT_DEV bool lane_pixel(const DevCamera &C, const DevFrame &F, uint32_t &x, uint32_t &y) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + wave;
-    const uint32_t tiles_x = (C.width + 7u) >> 3;
-    const uint32_t ty = gw / tiles_x, tx = gw - ty * tiles_x;
+    const uint32_t tx = blockIdx.x * (blockDim.x >> 6) + wave, ty = blockIdx.y;
     x = tx * 8u + (lane & 7u);
     y = F.row_begin + ty * 8u + (lane >> 3);
     return x < C.width && y < F.row_end;
 }
-
 enum { FK_REFL = 0, FK_REFR1 = 1, FK_REFR2 = 2, FK_PASS = 3 };
 
 // ------------------------------------------------------------------------------------------------
@@ -632,7 +633,7 @@ __global__ void __launch_bounds__(256, 6) rt_trace_kernel(const DevScene S, cons
         cnt.add(RT_CNT_PIXEL_PACK);
         f3 ro = ld3(C.position);
         DG_BEGIN(DG_RAYGEN)
-        f3 rd = camera_ray(C, px, py);
+        f3 rd = ld3(C.ray_dirs + 3u * (size_t)pos);  // Camera.ray_directions[pos] (src/renderer.rs:49)
         DG_END(DG_RAYGEN)
         f3 L = splat3(0.0f);      // light_color carried down
         f3 Cc = splat3(1.0f);     // contribution carried down
@@ -782,7 +783,7 @@ __global__ void __launch_bounds__(256, 6) rt_trace_kernel(const DevScene S, cons
     DG_END(DG_TOTAL)
 #ifdef RT_DIAG
     if ((threadIdx.x & 63u) == 0u && F.diag) {
-        const uint32_t gw_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const uint32_t gw_ = rt_block_index() * (blockDim.x >> 6) + (threadIdx.x >> 6);
         for (int i_ = 0; i_ < DG_N; i_++) F.diag[(size_t)gw_ * DG_N + i_] = (unsigned long long)dg.acc[i_];
     }
 #endif
@@ -987,7 +988,8 @@ __global__ void __launch_bounds__(256, 8) rt_march_kernel(const DevScene S, cons
     uint32_t px, py;
     const bool in_frame = lane_pixel(C, F, px, py);
     const f3 ro = ld3(C.position);
-    const f3 rd = camera_ray(C, px, py);  // lanes outside the frame compute a direction nobody uses
+    // Camera.ray_directions[pos] (src/renderer.rs:49); lanes outside the frame take pixel 0's direction, which nobody uses
+    const f3 rd = ld3(C.ray_dirs + 3u * (size_t)(in_frame ? py * C.width + px : 0u));
     RayCache rc;
     rc.slot = 0u;
     rc.trd = s_ray + threadIdx.x;
@@ -1083,6 +1085,17 @@ __global__ void __launch_bounds__(256, 8) rt_march_kernel(const DevScene S, cons
         store_pixel(F, pos, color);
     }
     flush_counters<EVENTS>(F, cnt, s_cnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Camera::calculate_ray_directions (src/camera.rs:128-157): the table of primary directions, once per camera change
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rt_raygen_kernel(const DevCamera C, float *__restrict__ out) {
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= C.width || y >= C.height) return;
+    const f3 d = camera_ray(C, x, y);
+    float *o = out + 3u * ((size_t)y * C.width + x);
+    o[0] = d.x; o[1] = d.y; o[2] = d.z;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -68,6 +68,7 @@ struct rt_ctx {
 
     DevBuf<uint32_t> rgba;
     DevBuf<float> accum;
+    DevBuf<float> ray_dirs;   // Camera.ray_directions: 3 floats per pixel
     DevBuf<uint32_t> counters;
     std::vector<uint32_t> h_counters;
     uint32_t last_blocks = 0, last_ncnt = 0;
@@ -168,8 +169,8 @@ hipError_t wait_external(rt_ctx *c, hipStream_t next) {
 #endif
 
 template <typename K>
-void launch(K kernel, uint32_t blocks, uint32_t threads, size_t lds, hipStream_t s, const DevScene &S, const DevCamera &C, const DevFrame &F) {
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, s, S, C, F);
+void launch(K kernel, dim3 grid, uint32_t threads, size_t lds, hipStream_t s, const DevScene &S, const DevCamera &C, const DevFrame &F) {
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, s, S, C, F);
 }
 
 // Scenes with many bounded objects get a bounding-volume hierarchy; small scenes keep the reference's linear scan.
@@ -227,7 +228,7 @@ void rt_destroy(rt_ctx *c) {
     c->objects.release(); c->materials.release(); c->lights.release(); c->sdfs.release(); c->textures.release();
     c->bvh_nodes.release(); c->unbounded.release();
     for (auto &t : c->tex_data) t.release();
-    c->rgba.release(); c->accum.release(); c->counters.release();
+    c->rgba.release(); c->accum.release(); c->ray_dirs.release(); c->counters.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->evc0) (void)hipEventDestroy(c->evc0);
@@ -385,16 +386,22 @@ int32_t rt_set_camera(rt_ctx *c, const rt_camera_desc *cam) {
     C.iv = make_xform(cam->inverse_view);
     for (int k = 0; k < 3; k++) C.position[k] = cam->position[k];
     const size_t px = (size_t)cam->width * cam->height;
+    RT_HIP(c, wait_external(c, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));   // a frame in flight still reads the previous table
     if (px != (size_t)C.width * C.height || !c->rgba.ptr) {
-        RT_HIP(c, wait_external(c, c->stream));
-        RT_HIP(c, hipStreamSynchronize(c->stream));
         RT_HIP(c, c->rgba.ensure(px));
         RT_HIP(c, c->accum.ensure(px * 4));
         RT_HIP(c, hipMemsetAsync(c->accum.ptr, 0, px * 4 * sizeof(float), c->stream));
     }
+    RT_HIP(c, c->ray_dirs.ensure(px * 3));
     C.width = cam->width; C.height = cam->height;
     C.inv_w = 1.0f / (float)cam->width;
     C.inv_h = 1.0f / (float)cam->height;
+    C.ray_dirs = c->ray_dirs.ptr;
+    // Camera::update ends with calculate_ray_directions (src/camera.rs:124): the table is rebuilt here, not per frame
+    hipLaunchKernelGGL(rt_raygen_kernel, dim3((cam->width + 63u) / 64u, (cam->height + 3u) / 4u), dim3(256), 0, c->stream, C, c->ray_dirs.ptr);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipStreamSynchronize(c->stream));   // renders may be launched on other streams
     c->has_camera = true;
     return RT_OK;
 }
@@ -432,8 +439,11 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
     const uint32_t threads = (S.ray_marching || maxd <= 8u) ? 256u : 64u;
     const uint32_t waves_per_block = threads / 64u;
     const uint32_t tiles_x = (c->camera.width + 7u) / 8u, tiles_y = (re - rb + 7u) / 8u;
-    const uint64_t n_waves = (uint64_t)tiles_x * tiles_y;
-    const uint32_t blocks = (uint32_t)((n_waves + waves_per_block - 1) / waves_per_block);
+    // 2-D grid: y = tile row, x = group of waves_per_block tile columns
+    const dim3 grid((tiles_x + waves_per_block - 1u) / waves_per_block, tiles_y);
+    const uint32_t blocks = grid.x * grid.y;
+    const uint64_t n_waves = (uint64_t)blocks * waves_per_block;  // diagnostic builds size their table by it
+    (void)n_waves;
     const uint32_t ncnt = (events ? (uint32_t)RT_CNT_COUNT : 0u) + 1u;
     RT_HIP(c, c->counters.ensure((size_t)blocks * ncnt));
 
@@ -459,11 +469,11 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
         F.leaf_slots = cache ? c->leaf_slots : 0u;
         const size_t lds = cache ? (size_t)c->leaf_slots * 3u * (threads + 1u) * sizeof(float) : 0u;
         if (cache) {
-            if (events) launch(rt_march_kernel<true, true>, blocks, threads, lds, s, S, c->camera, F);
-            else launch(rt_march_kernel<false, true>, blocks, threads, lds, s, S, c->camera, F);
+            if (events) launch(rt_march_kernel<true, true>, grid, threads, lds, s, S, c->camera, F);
+            else launch(rt_march_kernel<false, true>, grid, threads, lds, s, S, c->camera, F);
         } else {
-            if (events) launch(rt_march_kernel<true, false>, blocks, threads, 0, s, S, c->camera, F);
-            else launch(rt_march_kernel<false, false>, blocks, threads, 0, s, S, c->camera, F);
+            if (events) launch(rt_march_kernel<true, false>, grid, threads, 0, s, S, c->camera, F);
+            else launch(rt_march_kernel<false, false>, grid, threads, 0, s, S, c->camera, F);
         }
     } else {
         const size_t lds = (size_t)(maxd ? maxd : 1u) * 4u * threads * sizeof(float);
@@ -471,7 +481,7 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
         const int rsel = !c->has_refractive ? 0 : (maxd <= 8u ? 1 : 2);
         const int variant = (events ? 1 : 0) | (rsel << 1) | (S.bvh_nodes ? 8 : 0);
         switch (variant) {
-#define RT_CASE(V, E, R, D, B) case V: launch(rt_trace_kernel<E, R, D, B>, blocks, threads, lds, s, S, c->camera, F); break;
+#define RT_CASE(V, E, R, D, B) case V: launch(rt_trace_kernel<E, R, D, B>, grid, threads, lds, s, S, c->camera, F); break;
             RT_CASE(0, false, false, 1, false) RT_CASE(1, true, false, 1, false)
             RT_CASE(2, false, true, 8, false) RT_CASE(3, true, true, 8, false)
             RT_CASE(4, false, true, 32, false) RT_CASE(5, true, true, 32, false)
@@ -570,6 +580,15 @@ int32_t rt_read_accum(rt_ctx *c, float *out, size_t n_vec4) {
     RT_HIP(c, wait_external(c, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, hipMemcpy(out, c->accum.ptr, n_vec4 * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int32_t rt_read_ray_directions(rt_ctx *c, float *out, size_t n_vec3) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!c->has_camera) return fail(c, RT_ERR_STATE, "camera not set");
+    if (!out || n_vec3 != (size_t)c->camera.width * c->camera.height) return fail(c, RT_ERR_INVALID_ARGUMENT, "out must hold width*height directions");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipMemcpy(out, c->ray_dirs.ptr, n_vec3 * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

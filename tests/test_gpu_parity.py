@@ -237,6 +237,20 @@ def test_caller_owned_device_buffers_and_stream(pkg, ctx):
     assert np.array_equal(accum.cpu().numpy().view(np.uint32), ctx.read_accum().view(np.uint32))
 
 
+@pytest.mark.parametrize("name,size", [("scene3", (800, 600)), ("scene1", (333, 77)), ("scene4", (3840, 2160))])
+def test_ray_direction_table_equals_calculate_ray_directions(pkg, orc, ctx, name, size):
+    """rt_set_camera builds Camera.ray_directions on the device; every direction equals the oracle's, bit for bit."""
+    s = pkg.Scene(name)
+    ctx.load(s, *size)
+    got = ctx.read_ray_directions()
+    want = orc.ray_directions(s.camera(*size))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # a camera change rebuilds the table
+    cam = pkg.make_camera((1.0, 2.0, 3.0), (-0.2, -0.3, -1.0), 64, 40)
+    ctx.set_camera(cam)
+    assert np.array_equal(ctx.read_ray_directions().view(np.uint32), orc.ray_directions(cam).view(np.uint32))
+
+
 def test_page_locked_host_frame_receives_the_same_bytes(pkg, ctx):
     """rt_alloc_host_frame: rt_render into library-allocated page-locked memory delivers the bytes of the pageable path."""
     scene = pkg.Scene("scene1")
