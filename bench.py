@@ -192,9 +192,9 @@ def main() -> None:
                        "parallelism": f"{shard}-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": measured_traffic(args.workload),
-                         # the 157.3 TFLOP/s peak counts packed FMAs (4 flops per lane-instruction); bit-exact parity keeps
-                         # multiplies and adds unfused, so one flop per lane-instruction (a quarter of it) bounds this code
-                         "frac_of_unfused_unpacked_peak": round(achieved / (FP32_VALU_PEAK_TFLOPS / 4.0), 5),
+                         # the 157.3 TFLOP/s peak is one FMA (2 flops) per lane every 2 cycles; bit-exact parity keeps multiplies
+                         # and adds unfused, so one flop per lane-instruction (half of it) bounds this code
+                         "frac_of_unfused_peak": round(achieved / (FP32_VALU_PEAK_TFLOPS / 2.0), 5),
                          "kernel": "rt_march_kernel" if scene.desc.ray_marching else "rt_trace_kernel",
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
                          "note": "FP32 vector (VALU) roofline: this path has no dense contraction, so no MFMA"},
