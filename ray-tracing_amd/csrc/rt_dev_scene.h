@@ -28,6 +28,11 @@ struct DevObject {
     //   Cylinder p[0] radius, p[1] height
     //   Triangle p[0..2] v1, p[3..5] v2, p[6..8] v3
     float p[12];
+    // Bounding sphere of everything the object's intersect() can report (centre, squared radius with a safety margin), for
+    // the linear scan's wave-level rejection test; bounded == 0 (planes, composites): never rejected.
+    float bs[4];
+    int32_t bounded;
+    int32_t pad_[3];
 };
 
 struct DevMaterial {

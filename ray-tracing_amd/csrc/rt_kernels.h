@@ -222,8 +222,23 @@ RT_DEV int trace_closest(const DevScene &S, f3 ro, f3 rd, float &t_out, int &sub
     cnt.ray(ray_slot);
     float closest = RT_F32_MAX;
     int best = -1, best_sub = 0;
+    const float rd2 = dot(rd, rd);
+    // incoherent bounce rays of the diffuse mode almost never reject wave-wide: there the test is pure overhead
+    const bool cull = !EVENTS && (S.diffuse == 0u || __builtin_amdgcn_readfirstlane(ray_slot) == RT_CNT_RAYS_PRIMARY);
     for (uint32_t i = 0; i < n; i++) {
         const DevObject &o = S.objects[i];
+        if (cull && o.bounded) {
+            // Wave-level rejection (timed variant only; the counting variant runs every candidate test the reference runs).
+            // The object lies inside the sphere (c, R): a ray whose line passes farther than R from c, or that starts
+            // outside the sphere with c behind it, can only report "no hit" or a negative distance, which the acceptance
+            // rule below discards anyway.  |oc x rd|^2 = |oc|^2 |rd|^2 - (oc . rd)^2; the 1e-5 |oc|^2 term covers the
+            // rounding of that difference.  The candidate test is skipped only when every lane of the wavefront rejects.
+            const f3 oc = ld3(o.bs) - ro;
+            const float oc2 = dot(oc, oc), b = dot(oc, rd);
+            const float r2 = o.bs[3] + 1e-5f * oc2;
+            const bool miss = (oc2 * rd2 - b * b > r2 * rd2) || (b < 0.0f && oc2 > r2);
+            if (__ballot(!miss) == 0ull) continue;
+        }
         float t = 0.0f;
         int sub = 0;
         bool ok = false;

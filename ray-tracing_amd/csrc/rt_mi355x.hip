@@ -132,6 +132,21 @@ DevObject make_dev_object(const rt_object &o) {
             break;
         default: break;
     }
+    // bounding sphere around the (already padded) world box of rt_object_bounds; radius rounded up generously
+    RtAabb box;
+    g.bounded = 0;
+    g.bs[0] = g.bs[1] = g.bs[2] = 0.0f; g.bs[3] = 3.0e38f;
+    if (rt_object_bounds(o, box)) {
+        double r2 = 0.0;
+        for (int k = 0; k < 3; k++) {
+            const double c = 0.5 * ((double)box.lo[k] + (double)box.hi[k]), h = 0.5 * ((double)box.hi[k] - (double)box.lo[k]);
+            g.bs[k] = (float)c;
+            const double hh = h + std::fabs(c - (double)g.bs[k]);   // the centre was rounded to binary32
+            r2 += hh * hh;
+        }
+        const float r2f = (float)(r2 * 1.002 + 1e-12);
+        if (std::isfinite(r2f)) { g.bs[3] = r2f; g.bounded = 1; }
+    }
     return g;
 }
 
