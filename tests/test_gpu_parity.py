@@ -539,6 +539,62 @@ def test_hierarchy_with_every_primitive_kind_shadows_textures_and_glass(pkg, orc
     assert st["bvh_node"] > 0 and all(cref[k] > 0 for k in ("hit_sphere", "hit_cuboid", "hit_cylinder", "hit_cone", "hit_triangle", "hit_plane", "refraction", "tex_fetch"))
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_small_scenes_through_the_linear_scan(pkg, orc, ctx, seed):
+    """Random scenes of 3-14 objects of every kind (below the hierarchy threshold: linear scan with the wave-level
+    bounding-sphere rejection), cameras sometimes inside an object, a directional light whose direction is not unit
+    length, shadows and glass: the timed variant, the counting variant and the oracle agree bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    mats = [make_material(pkg, albedo=tuple(rng.uniform(0.2, 0.9, 3)), roughness=float(rng.uniform(0.2, 1.0)), ambience=0.4,
+                          shininess=float(rng.uniform(3, 120)), specular=float(rng.uniform(0.2, 1.5))) for _ in range(5)]
+    mats.append(make_material(pkg, albedo=(0.9, 0.95, 1.0), kind=pkg.RT_REFRACTIVE, transparency=0.9, refraction_index=1.2, reflectivity=0.1))
+    mats.append(make_material(pkg, albedo=(0.5, 0.5, 0.5), texture=int(rng.integers(0, 4)), roughness=0.7, ambience=0.4))
+    objs = []
+    if rng.random() < 0.7:
+        objs.append(make_object(pkg, pkg.RT_PLANE, int(rng.integers(0, 7)), normal=(0, 1, 0), point=(0, -0.6, 0),
+                                max_dist=(float(rng.uniform(2, 9)), float(rng.uniform(2, 9))), has_max_dist=int(rng.integers(0, 2))))
+    n = int(rng.integers(3, 14))
+    for i in range(n):
+        pos = (float(rng.uniform(-3, 3)), float(rng.uniform(-0.3, 2.0)), float(rng.uniform(-4, 2)))
+        rot = tuple(float(a) for a in rng.uniform(-180, 180, 3))
+        m = int(rng.integers(0, 7))
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            objs.append(make_object(pkg, pkg.RT_SPHERE, m, position=pos, rotation_axis=rot, radius=float(rng.uniform(0.2, 1.5))))
+        elif kind == 1:
+            objs.append(make_object(pkg, pkg.RT_CUBOID, m, position=pos, rotation_axis=rot, dimension=tuple(float(a) for a in rng.uniform(0.15, 0.9, 3))))
+        elif kind == 2:
+            objs.append(make_object(pkg, pkg.RT_CYLINDER, m, position=pos, rotation_axis=rot, radius=0.3, height=1.0))
+        elif kind == 3:
+            objs.append(make_object(pkg, pkg.RT_CONE, m, position=pos, rotation_axis=rot, radius=float(rng.uniform(0.2, 0.8)), height=float(rng.uniform(0.4, 1.5))))
+        else:
+            v1 = np.array(pos)
+            objs.append(make_object(pkg, pkg.RT_TRIANGLE, m, v1=tuple(v1), v2=tuple(v1 + rng.uniform(-1.5, 1.5, 3)), v3=tuple(v1 + rng.uniform(-1.5, 1.5, 3))))
+    lights = [make_light(pkg, pkg.RT_POSITIONAL, (1, 1, 1), tuple(float(a) for a in rng.uniform(-4, 4, 3) + np.array([0, 5, 0])), 25.0),
+              make_light(pkg, pkg.RT_DIRECTIONAL, (1, 0.9, 0.8), (0.6, -2.0, -0.4), 0.7)]        # |direction| = 2.1
+    sb = SceneBuilder(pkg, objs, mats, lights, n_textures=4, max_ray_bounces=int(rng.integers(1, 7)), shadow_casting=int(rng.integers(0, 2)),
+                      ambient_color=(0.05, 0.08, 0.12))
+    if seed % 3 == 0:   # camera at an object's position: inside it for spheres, cuboids and cylinders
+        o = objs[-1]
+        eye = tuple(o.position) if o.kind != pkg.RT_TRIANGLE else (0.0, 0.5, 0.0)
+    else:
+        eye = (float(rng.uniform(-2, 2)), float(rng.uniform(0.5, 3)), float(rng.uniform(3, 7)))
+    cam = pkg.make_camera(eye, (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.4, 0.1)), -1.0), 136, 88)
+    tex = pkg.load_textures()
+    for i, t in enumerate(tex):
+        ctx.set_texture(i, t)
+    ctx.set_scene(sb.desc)
+    ctx.set_camera(cam)
+    rgba, lin, st = gpu_frame(ctx, events=True)
+    ref = orc.render(sb.desc, cam, tex, want_counters=True, n_threads=8)
+    assert_parity(rgba, ref["rgba"], lin, ref["accum"], what=f"random scene {seed}")
+    assert {k: st[k] for k in pkg.COUNTER_NAMES} == dict(zip(pkg.COUNTER_NAMES, ref["counters"]))
+    ctx.reset_accum()
+    ctx.render_device(frame_index=1)                          # the timed variant (with the rejection test)
+    assert ctx.stats()["rays_total"] == st["rays_total"]
+    assert np.array_equal(ctx.read_accum().view(np.uint32), lin.view(np.uint32))
+
+
 def test_resolve_after_external_accumulation(pkg, orc, ctx):
     """rt_resolve_device: the accumulate tail of render_chunk on an accumulator that was summed outside the library
     (sample-index sharding over GPUs followed by an all-reduce)."""
