@@ -595,6 +595,65 @@ def test_random_small_scenes_through_the_linear_scan(pkg, orc, ctx, seed):
     assert np.array_equal(ctx.read_accum().view(np.uint32), lin.view(np.uint32))
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_sdf_scenes_through_the_march_kernel(pkg, orc, ctx, seed):
+    """Random ray-marching scenes: leaves of every kind, Union / Substraction nested up to two levels, random SDF lists
+    (with cones and triangles, whose sdf is f32::MAX), textured and plain materials."""
+    rng = np.random.default_rng(2000 + seed)
+    mats = [make_material(pkg, albedo=tuple(rng.uniform(0.2, 0.9, 3)), ambience=0.4, shininess=float(rng.uniform(3, 90)),
+                          specular=float(rng.uniform(0.2, 1.5))) for _ in range(4)]
+    mats.append(make_material(pkg, albedo=(0.5, 0.5, 0.5), texture=int(rng.integers(0, 4)), ambience=0.4))
+    objs = [make_object(pkg, pkg.RT_PLANE, int(rng.integers(0, 5)), normal=(0, 1, 0), point=(0, 0, 0))]
+    n_leaves = int(rng.integers(3, 9))
+    for i in range(n_leaves):
+        pos = (float(rng.uniform(-2.5, 2.5)), float(rng.uniform(0.2, 1.6)), float(rng.uniform(-3, 1)))
+        rot = tuple(float(a) for a in rng.uniform(-60, 60, 3))
+        m = int(rng.integers(0, 5))
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            objs.append(make_object(pkg, pkg.RT_SPHERE, m, position=pos, rotation_axis=rot, radius=float(rng.uniform(0.3, 0.9))))
+        elif kind == 1:
+            objs.append(make_object(pkg, pkg.RT_CUBOID, m, position=pos, rotation_axis=rot, dimension=tuple(float(a) for a in rng.uniform(0.2, 0.7, 3))))
+        elif kind == 2:
+            objs.append(make_object(pkg, pkg.RT_CYLINDER, m, position=pos, rotation_axis=rot, radius=float(rng.uniform(0.2, 0.5)), height=float(rng.uniform(0.5, 1.4))))
+        elif kind == 3:
+            objs.append(make_object(pkg, pkg.RT_CONE, m, position=pos, rotation_axis=rot, radius=0.5, height=1.0))
+        else:
+            v1 = np.array(pos)
+            objs.append(make_object(pkg, pkg.RT_TRIANGLE, m, v1=tuple(v1), v2=tuple(v1 + 1.0), v3=tuple(v1 - 0.5)))
+    leaves = list(range(len(objs)))
+    level1 = []
+    for _ in range(int(rng.integers(1, 4))):
+        a, b = (int(x) for x in rng.choice(leaves, 2, replace=False))
+        objs.append(make_object(pkg, pkg.RT_UNION if rng.random() < 0.6 else pkg.RT_SUBSTRACTION, 0, first=a, second=b))
+        level1.append(len(objs) - 1)
+    level2 = []
+    for _ in range(int(rng.integers(0, 3))):
+        a = int(rng.choice(level1)); b = int(rng.choice(leaves))
+        objs.append(make_object(pkg, pkg.RT_UNION if rng.random() < 0.5 else pkg.RT_SUBSTRACTION, 0, first=a, second=b))
+        level2.append(len(objs) - 1)
+    pool = leaves + level1 + level2
+    sdfs = [int(x) for x in rng.choice(pool, size=int(rng.integers(2, min(7, len(pool)) + 1)), replace=False)]
+    if level2 and level2[0] not in sdfs:
+        sdfs.append(level2[0])
+    lights = [make_light(pkg, pkg.RT_DIRECTIONAL, (1, 1, 1), (-0.4, -0.8, -0.45), 2.0)]
+    if rng.random() < 0.5:
+        lights.append(make_light(pkg, pkg.RT_POSITIONAL, (1, 0.8, 0.6), (2.0, 4.0, 3.0), 12.0))
+    sb = SceneBuilder(pkg, objs, mats, lights, sdfs=sdfs, n_textures=4, ray_marching=1, max_ray_bounces=4, ambient_color=(0.1, 0.12, 0.2))
+    cam = pkg.make_camera((float(rng.uniform(-1, 1)), float(rng.uniform(1.0, 3.0)), float(rng.uniform(3, 6))),
+                          (float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.4, -0.1)), -1.0), 120, 80)
+    tex = pkg.load_textures()
+    for i, t in enumerate(tex):
+        ctx.set_texture(i, t)
+    ctx.set_scene(sb.desc)
+    ctx.set_camera(cam)
+    rgba, lin, st = gpu_frame(ctx, events=True)
+    ref = orc.render(sb.desc, cam, tex, want_counters=True, n_threads=8)
+    assert_parity(rgba, ref["rgba"], lin, ref["accum"], what=f"random sdf scene {seed} sdfs {sdfs}")
+    assert {k: st[k] for k in pkg.COUNTER_NAMES} == dict(zip(pkg.COUNTER_NAMES, ref["counters"]))
+    assert st["march_step"] > 0
+
+
 def test_resolve_after_external_accumulation(pkg, orc, ctx):
     """rt_resolve_device: the accumulate tail of render_chunk on an accumulator that was summed outside the library
     (sample-index sharding over GPUs followed by an all-reduce)."""
