@@ -595,6 +595,41 @@ def test_random_small_scenes_through_the_linear_scan(pkg, orc, ctx, seed):
     assert np.array_equal(ctx.read_accum().view(np.uint32), lin.view(np.uint32))
 
 
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_random_scenes_in_the_random_number_modes(pkg, orc, ctx, seed):
+    """Diffuse path tracing and the roughness-jitter mode on random small scenes (emissive, glass and plain materials),
+    three accumulated samples with a fixed seed: accumulator and bytes equal the oracle's after every sample."""
+    rng = np.random.default_rng(3000 + seed)
+    mats = [make_material(pkg, albedo=tuple(rng.uniform(0.2, 0.9, 3)), roughness=float(rng.uniform(0.1, 1.0)),
+                          emission_power=float(rng.choice([0.0, 0.0, 4.0]))) for _ in range(5)]
+    mats.append(make_material(pkg, albedo=(0.9, 0.95, 1.0), kind=pkg.RT_REFRACTIVE, transparency=0.9, refraction_index=1.3, reflectivity=0.1))
+    objs = [make_object(pkg, pkg.RT_PLANE, 0, normal=(0, 1, 0), point=(0, -0.5, 0))]
+    for i in range(int(rng.integers(3, 10))):
+        pos = (float(rng.uniform(-3, 3)), float(rng.uniform(-0.2, 1.5)), float(rng.uniform(-4, 1)))
+        m = int(rng.integers(0, 6))
+        if i % 2 == 0:
+            objs.append(make_object(pkg, pkg.RT_SPHERE, m, position=pos, radius=float(rng.uniform(0.3, 1.0))))
+        else:
+            objs.append(make_object(pkg, pkg.RT_CUBOID, m, position=pos, rotation_axis=tuple(float(a) for a in rng.uniform(-90, 90, 3)),
+                                    dimension=tuple(float(a) for a in rng.uniform(0.2, 0.8, 3))))
+    lights = [make_light(pkg, pkg.RT_POSITIONAL, (1, 1, 1), (2.0, 5.0, 3.0), 20.0)]
+    diffuse = seed % 2
+    sb = SceneBuilder(pkg, objs, mats, lights, max_ray_bounces=int(rng.integers(2, 7)), diffuse=diffuse, enable_accumulation=1 - diffuse if seed != 4 else 1,
+                      shadow_casting=int(rng.integers(0, 2)), ambient_color=(0.4, 0.6, 0.9))
+    cam = pkg.make_camera((0.3, 1.5, 5.0), (0.0, -0.2, -1.0), 112, 72)
+    ctx.set_scene(sb.desc)
+    ctx.set_camera(cam)
+    ctx.reset_accum()
+    acc = np.zeros((72, 112, 4), dtype=np.float32)
+    for f in (1, 2, 3):
+        rgba = ctx.render(frame_index=f, accumulate=True, reset_accum=False, seed=4242 + seed)
+        ref = orc.render(sb.desc, cam, (), frame_index=f, accumulate=True, seed=4242 + seed, accum=acc, n_threads=8)
+        assert_parity(rgba, ref["rgba"], ctx.read_accum(), acc, what=f"random-mode scene {seed} sample {f}")
+    other = ctx.render(frame_index=1, accumulate=True, reset_accum=True, seed=1)
+    first = orc.render(sb.desc, cam, (), frame_index=1, accumulate=True, seed=4242 + seed)
+    assert not np.array_equal(other, first["rgba"]), "the seed has no effect"
+
+
 @pytest.mark.parametrize("seed", list(range(8)))
 def test_random_sdf_scenes_through_the_march_kernel(pkg, orc, ctx, seed):
     """Random ray-marching scenes: leaves of every kind, Union / Substraction nested up to two levels, random SDF lists
