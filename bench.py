@@ -63,9 +63,15 @@ def main() -> None:
     # not what the rows / samples modes are written for)
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     device_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1 makes a single rank go through the process group as well (its barrier and reductions), which
+    # rehearses the RCCL calls of the multi-GPU launch on a one-GPU box
+    use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
@@ -88,7 +94,7 @@ def main() -> None:
     my_rows = pkg.shard_rows(height, rank, world)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -159,7 +165,7 @@ def main() -> None:
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     r = torch.tensor([float(rays_rank)], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
     elapsed_max = float(t.item())
@@ -202,11 +208,11 @@ def main() -> None:
         if scene.desc.ray_marching:
             # one sdfs() call evaluates the whole SDF list once (src/ray_marching/ray_marching.rs:24-107)
             out["config"]["sdf_list_evals_per_s"] = round(st["sdfs_call"] / (kernel_ms * 1e-3), 1)
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:   # a reported baseline of the single-GPU line only
             out["cpu_baseline"] = cpu_baseline(pkg, scene, width, height, accumulate)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
