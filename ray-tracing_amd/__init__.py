@@ -198,6 +198,9 @@ def host() -> C.CDLL:
                                            C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.POINTER(rt_object),
                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
         h.rth_render_animation.restype = C.c_int32
+        h.rth_load_image.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint8)), C.c_char_p, C.c_size_t]
+        h.rth_load_image.restype = C.c_int32
+        h.rth_free_image.argtypes = [C.POINTER(C.c_uint8)]; h.rth_free_image.restype = None
         _host = h
     return _host
 
@@ -226,6 +229,19 @@ def load_textures(directory: str = TEXTURE_DIR) -> list:
             out.append(np.ascontiguousarray(np.asarray(img, dtype=np.uint8)))
         _tex_cache[directory] = out
     return _tex_cache[directory]
+
+
+def load_image(path: str) -> np.ndarray:
+    """The host mirror's load_image (ImageUtils::load_image, src/utils/image.rs:13-29): PNG or binary PPM file ->
+    (h, w, 3) uint8.  Raises ValueError with the loader's message otherwise (JPEG files are refused: see load_textures)."""
+    w, h, ptr = C.c_uint32(), C.c_uint32(), C.POINTER(C.c_uint8)()
+    err = C.create_string_buffer(512)
+    if host().rth_load_image(os.fsencode(path), C.byref(w), C.byref(h), C.byref(ptr), err, len(err)) != 0:
+        raise ValueError(err.value.decode(errors="replace"))
+    try:
+        return np.ctypeslib.as_array(ptr, shape=(h.value, w.value, 3)).copy()
+    finally:
+        host().rth_free_image(ptr)
 
 
 class Scene:

@@ -62,12 +62,17 @@ struct Material {
 };
 
 // src/objects.rs:104-111; bytes are tightly packed RGB8 as ImageUtils::load_image leaves them
-// (src/utils/image.rs:13-29).  Decoding image files stays on the caller's side.
+// (src/utils/image.rs:13-29).
 struct Texture {
     std::string path;
     uint32_t width = 0, height = 0;
     std::vector<uint8_t> bytes;
 };
+
+// ImageUtils::load_image (src/utils/image.rs:13-29) for the formats whose decoding is exact: PNG (8-bit grey, RGB,
+// palette, with or without alpha; 1/2/4-bit grey and palette; not interlaced) and binary PPM.  Alpha is dropped and grey
+// replicated, as `into_rgb8()` does.  JPEG files are refused (their pixels depend on the decoder).  Returns "" or a message.
+std::string load_image(const std::string &path, Texture &out);
 
 // src/light.rs:3-33
 struct Light {
@@ -196,8 +201,8 @@ struct Renderer {
 };
 
 // The reference's demo scenes as data (src/bin/scene1.rs .. scene4.rs, construction-time state) and the
-// two synthetic benchmark scenes.  Texture slots are declared (n_textures) but carry no bytes: image
-// decoding stays with the caller, who attaches them with Scene::with_texture / rt_set_texture.
+// two synthetic benchmark scenes.  Texture slots are declared (n_textures) but carry no bytes: the caller
+// attaches them with Scene::with_texture / rt_set_texture (load_image above, or its own decoder for JPEG).
 namespace scenes {
 struct Built { Scene scene; Camera camera; bool renderer_accumulation = false; };
 Built scene1();
@@ -236,4 +241,7 @@ int32_t rth_render_animation(rth_scene *s, uint32_t width, uint32_t height, uint
                              const uint32_t *tex_w, const uint32_t *tex_h, const uint8_t *const *tex_rgb8, int32_t device_id,
                              uint8_t *img_out, rt_object *objects_out, uint64_t *full_uploads, uint64_t *object_updates,
                              char *err, size_t err_len);
+// load_image: *rgb8 receives width*height*3 bytes allocated by the library (release with rth_free_image)
+int32_t rth_load_image(const char *path, uint32_t *width, uint32_t *height, uint8_t **rgb8, char *err, size_t err_len);
+void rth_free_image(uint8_t *rgb8);
 }

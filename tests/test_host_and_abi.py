@@ -154,3 +154,59 @@ def test_shard_rows_partitions_every_row_once(pkg):
             for a, b in zip(bands, bands[1:]):
                 assert a[1] == b[0]
             assert all(b % 8 == 0 or b == h for _, b in bands)
+
+
+def test_host_load_image_matches_pil_on_the_lossless_formats(pkg, tmp_path):
+    """load_image (ImageUtils::load_image, src/utils/image.rs:13-29): PNG decoding is lossless, so the C++ loader must
+    give PIL's RGB bytes exactly -- on the reference's two PNG textures and on synthetic files of every colour type."""
+    from PIL import Image
+    for name in ("chess.png", "wood.png"):   # RGB and RGBA (alpha dropped, like into_rgb8)
+        path = os.path.join(pkg.TEXTURE_DIR, name)
+        want = np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
+        got = pkg.load_image(path)
+        assert got.shape == want.shape and np.array_equal(got, want), name
+    rng = np.random.default_rng(7)
+    smooth = (np.add.outer(np.arange(37) * 5, np.arange(53) * 3)[..., None] + np.array([0, 40, 90])) % 256   # exercises the row filters
+    noise = rng.integers(0, 256, size=(37, 53, 4))
+    cases = {
+        "rgb": Image.fromarray(smooth.astype(np.uint8), "RGB"),
+        "rgba": Image.fromarray(noise.astype(np.uint8), "RGBA"),
+        "grey": Image.fromarray(smooth[..., 0].astype(np.uint8), "L"),
+        "grey_alpha": Image.fromarray(noise[..., :2].astype(np.uint8), "LA"),
+        "palette": Image.fromarray(smooth.astype(np.uint8), "RGB").quantize(200),
+        "palette4": Image.fromarray(smooth.astype(np.uint8), "RGB").quantize(13),
+        "bilevel": Image.fromarray((smooth[..., 0] > 128)),
+    }
+    for name, img in cases.items():
+        path = str(tmp_path / f"{name}.png")
+        img.save(path, optimize=(name != "rgb"))
+        want = np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
+        assert np.array_equal(pkg.load_image(path), want), name
+    ppm = str(tmp_path / "a.ppm")
+    with open(ppm, "wb") as fh:
+        fh.write(b"P6\n# comment\n53 37\n255\n" + smooth.astype(np.uint8).tobytes())
+    assert np.array_equal(pkg.load_image(ppm), smooth.astype(np.uint8))
+
+
+def test_host_load_image_refuses_what_it_cannot_decode_exactly(pkg, tmp_path):
+    from PIL import Image
+    with pytest.raises(ValueError, match="JPEG"):
+        pkg.load_image(os.path.join(pkg.TEXTURE_DIR, "stone3.jpg"))
+    with pytest.raises(ValueError, match="cannot open"):
+        pkg.load_image(str(tmp_path / "missing.png"))
+    good = str(tmp_path / "good.png")
+    Image.fromarray(np.zeros((9, 9, 3), dtype=np.uint8), "RGB").save(good)
+    data = bytearray(open(good, "rb").read())
+    data[40] ^= 0xFF                                   # inside the pixel data: the chunk checksum catches it
+    bad = str(tmp_path / "bad.png")
+    open(bad, "wb").write(bytes(data))
+    with pytest.raises(ValueError, match="checksum"):
+        pkg.load_image(bad)
+    open(bad, "wb").write(bytes(data[:30]))
+    with pytest.raises(ValueError):
+        pkg.load_image(bad)
+    inter = str(tmp_path / "interlaced.png")
+    wide = Image.fromarray(np.zeros((9, 9), dtype=np.uint16))
+    wide.save(inter)
+    with pytest.raises(ValueError, match="bit depth"):
+        pkg.load_image(inter)
