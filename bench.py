@@ -45,8 +45,8 @@ WORKLOADS = {
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="default: 200 frames (5 for the 64-spp workload)")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 20 frames (1 for the 64-spp workload)")
     ap.add_argument("--workload", default="scene3_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--shard", default=None, choices=["frames", "rows", "samples"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,6 +80,11 @@ def main() -> None:
 
     pkg = graft.load_package()
     scene_name, width, height, bounces, accumulate, spp, default_shard, description = WORKLOADS[args.workload]
+    # a 4K frame takes 0.1-1.3 ms: 200 timed frames after 20 warm-up frames let the clocks settle and still take well under a second
+    if args.steps is None:
+        args.steps = 200 if spp == 1 else 5
+    if args.warmup is None:
+        args.warmup = 20 if spp == 1 else 1
     shard = args.shard or default_shard
     scene = pkg.Scene(scene_name)
     if bounces is not None:
