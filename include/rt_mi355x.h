@@ -194,7 +194,7 @@ typedef enum rt_counter {
 typedef struct rt_stats {
     uint64_t rays_total;     /* all trace_ray + march_ray invocations of the last render (always filled) */
     uint64_t counters[RT_CNT_COUNT]; /* per-kind rays and events; zero unless collect_events was set    */
-    double last_kernel_ms;   /* HIP-event time of the last render's kernel(s) on the launch stream */
+    double last_kernel_ms;   /* HIP-event time of the last render's kernel(s) on the launch stream (0 if no_timing) */
     double last_copy_ms;     /* D2H time of the last rt_render (0 for rt_render_device)            */
     uint64_t frames_rendered;
 } rt_stats;
@@ -207,7 +207,8 @@ typedef struct rt_render_params {
     uint32_t row_end;
     int32_t accumulate;      /* Renderer.enable_accumulation                                         */
     int32_t collect_events;  /* 1: also fill the event slots of rt_stats (slower kernel variant)     */
-    int32_t reserved;
+    int32_t no_timing;       /* 1: do not bracket the launch with timing events (about 6 us per launch on the
+                              * stream); rt_stats.last_kernel_ms then reads 0 for it                   */
     uint64_t seed;           /* keys the counter-based generator that stands in for ThreadRng        */
 } rt_render_params;
 

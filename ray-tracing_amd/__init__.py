@@ -118,7 +118,7 @@ class rt_stats(C.Structure):
 
 class rt_render_params(C.Structure):
     _fields_ = [("frame_index", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("accumulate", C.c_int32),
-                ("collect_events", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64)]
+                ("collect_events", C.c_int32), ("no_timing", C.c_int32), ("seed", C.c_uint64)]
 
 
 # every symbol include/rt_mi355x.h declares
@@ -359,7 +359,8 @@ class Context:
         self._check(self._l.rt_free_host_frame(self._ctx, frame.ctypes.data), "rt_free_host_frame")
 
     def render_device(self, frame_index: int = 1, accumulate: bool = False, seed: int = 0x5EED, rows: Optional[tuple] = None,
-                      collect_events: bool = False, d_rgba8: int = 0, d_accum: int = 0, stream: Optional[int] = None):
+                      collect_events: bool = False, d_rgba8: int = 0, d_accum: int = 0, stream: Optional[int] = None,
+                      no_timing: bool = False):
         """rt_render_device: asynchronous launch into device buffers (0 = the context's own).
 
         `stream` is a hipStream_t handle used as is (0 is HIP's default stream); None selects the context's own stream."""
@@ -367,6 +368,7 @@ class Context:
         p.frame_index = frame_index
         p.accumulate = int(accumulate)
         p.collect_events = int(collect_events)
+        p.no_timing = int(no_timing)
         p.seed = seed
         if rows is not None:
             p.row_begin, p.row_end = rows

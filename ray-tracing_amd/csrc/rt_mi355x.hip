@@ -72,6 +72,7 @@ struct rt_ctx {
     DevBuf<uint32_t> counters;
     std::vector<uint32_t> h_counters;
     uint32_t last_blocks = 0, last_ncnt = 0;
+    bool kernel_timed = false;           // the last launch was bracketed by ev0 / ev1
     bool last_events = false, timed = false;
     hipStream_t last_stream = nullptr;
     double last_copy_ms = 0.0;
@@ -477,7 +478,9 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
     F.diag = s_diag;
 #endif
 
-    RT_HIP(c, hipEventRecord(c->ev0, s));
+    // the two timing events cost about 6 us per launch on the stream; callers that time their own stream opt out
+    const bool time_kernel = p->no_timing == 0;
+    if (time_kernel) RT_HIP(c, hipEventRecord(c->ev0, s));
     if (S.ray_marching) {
         // up to 16 leaves (48 KiB of LDS per workgroup) keep their object-space rays in LDS during the march loop
         const bool cache = c->leaf_slots >= 1u && c->leaf_slots <= (uint32_t)RT_MARCH_CACHE_MAX_SLOTS;
@@ -508,7 +511,8 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
         }
     }
     RT_HIP(c, hipGetLastError());
-    RT_HIP(c, hipEventRecord(c->ev1, s));
+    if (time_kernel) RT_HIP(c, hipEventRecord(c->ev1, s));
+    c->kernel_timed = time_kernel;
     c->last_blocks = blocks; c->last_ncnt = ncnt; c->last_events = events; c->timed = true; c->last_stream = s;
 #ifdef RT_DIAG
     if (getenv("RT_DIAG_PRINT")) {
@@ -615,7 +619,7 @@ int32_t rt_get_stats(rt_ctx *c, rt_stats *out) {
     if (c->timed) {
         RT_HIP(c, hipStreamSynchronize(c->last_stream));
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) out->last_kernel_ms = ms;
+        if (c->kernel_timed && hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) out->last_kernel_ms = ms;
         const size_t n = (size_t)c->last_blocks * c->last_ncnt;
         c->h_counters.resize(n);
         RT_HIP(c, hipMemcpy(c->h_counters.data(), c->counters.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost));

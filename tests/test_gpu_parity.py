@@ -269,6 +269,24 @@ def test_page_locked_host_frame_receives_the_same_bytes(pkg, ctx):
     assert l.rt_alloc_host_frame(ctx._ctx, 0, C.byref(C.c_void_p())) == -1
 
 
+def test_launch_without_timing_events_renders_the_same_frame(pkg, ctx):
+    """rt_render_params.no_timing: the launch is not bracketed by timing events; the frame and the ray count are unchanged and
+    rt_stats.last_kernel_ms reads 0 until a timed launch follows."""
+    import torch
+    scene = pkg.Scene("scene1")
+    ctx.load(scene, 160, 96)
+    want = ctx.render(frame_index=1, reset_accum=True)
+    rays = ctx.stats()["rays_total"]
+    assert ctx.stats()["last_kernel_ms"] > 0.0
+    rgba = torch.zeros((96, 160, 4), dtype=torch.uint8, device="cuda")
+    ctx.render_device(frame_index=1, d_rgba8=rgba.data_ptr(), no_timing=True)
+    st = ctx.stats()
+    assert st["last_kernel_ms"] == 0.0 and st["rays_total"] == rays
+    assert np.array_equal(rgba.cpu().numpy(), want)
+    ctx.render_device(frame_index=1, d_rgba8=rgba.data_ptr())
+    assert ctx.stats()["last_kernel_ms"] > 0.0
+
+
 def test_error_behaviour_matches_the_reference_panics(pkg, ctx):
     """Out-of-range indices (a panic in the reference) and call-order mistakes come back as negative statuses with a message."""
     l = pkg.lib()

@@ -7,7 +7,7 @@ WL=${2:-scene3_4k}
 OUT=gpurun_out/prof_${TAG}_${WL}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout -k 10 180 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --workload "$WL" --steps 30 --warmup 3 --no-cpu-baseline > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err" || exit 1
+timeout -k 10 180 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --workload "$WL" --no-cpu-baseline > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err" || exit 1
 for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY" \
             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_FLAT SQ_INST_CYCLES_VMEM" \
             "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum" \
