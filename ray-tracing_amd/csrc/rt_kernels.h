@@ -606,12 +606,15 @@ RT_DEV void flush_counters(const DevFrame &F, Cnt<EVENTS> &cnt, uint32_t *s_cnt)
     for (uint32_t i = threadIdx.x; i < (uint32_t)N; i += blockDim.x) F.counters[rt_block_index() * (uint32_t)N + i] = s_cnt[i];
 }
 
-// pixel of this lane: a wavefront owns one 8x8 tile; blockIdx.y is the tile row, blockIdx.x * waves + wave the tile column
-// (a 2-D grid: no integer division).
+// pixel of this lane: a wavefront owns one 8x8 tile; blockIdx.y counts the tile rows from the bottom of the band,
+// blockIdx.x * waves + wave is the tile column (a 2-D grid: no integer division).
+// Workgroups start in launch order and a launch ends when its last workgroup does.  Rows from the bottom up put the sky --
+// the cheap rows of most frames -- last, so the launch does not end on a few expensive workgroups with the chip idle
+// (measured against top-down on the 4K workloads: scene3 -6 %, scene1 -7 %, scene4 -18 %, tex4 and scene2 +1 %).
 RT_DEV bool lane_pixel(const DevCamera &C, const DevFrame &F, uint32_t &x, uint32_t &y) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t tx = blockIdx.x * (blockDim.x >> 6) + wave, ty = blockIdx.y;
+    const uint32_t tx = blockIdx.x * (blockDim.x >> 6) + wave, ty = gridDim.y - 1u - blockIdx.y;
     x = tx * 8u + (lane & 7u);
     y = F.row_begin + ty * 8u + (lane >> 3);
     return x < C.width && y < F.row_end;
