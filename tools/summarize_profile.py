@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Condenses a tools/profile.sh output directory into a small text summary (kept under profiles/)."""
 import csv
+import json
 import glob
 import os
 import sys
@@ -24,6 +25,19 @@ def main():
             r = v[0][1]
             out.append(f"{k[:90]}, {len(ds)}, {sum(ds) / len(ds):.0f}, {min(ds)}, {max(ds)}, {r.get('VGPR_Count')}, {r.get('SGPR_Count')}, "
                        f"{r.get('LDS_Block_Size')}, {r.get('Scratch_Size')}, {r.get('Grid_Size')}, {r.get('Workgroup_Size')}")
+        # the timed steps of bench.py are the last `steps` dispatches of the render kernel before the counting variant's
+        # single dispatch; the ones before them are the clock pre-warm and the warm-up steps
+        try:
+            steps = json.load(open(os.path.join(d, "bench_under_trace.json")))["steps"]
+        except (OSError, ValueError, KeyError):
+            steps = None
+        if steps:
+            for k, v in by.items():
+                if "rt_" in k and "<false" in k and len(v) > steps:
+                    v.sort(key=lambda x: int(x[1]["Start_Timestamp"]))
+                    timed = [x[0] for x in v[-(steps + 1):-1]]   # the very last one is bench.py's untimed ray-count pass
+                    out.append(f"== timed steps only: {k[:90]}: last {len(timed)} dispatches before the final one, mean {sum(timed) / len(timed):.0f} ns, "
+                               f"min {min(timed)}, max {max(timed)}")
     for f in sorted(glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
         rows = list(csv.DictReader(open(f)))
         agg = defaultdict(lambda: defaultdict(list))
