@@ -663,7 +663,10 @@ __global__ void __launch_bounds__(256, BVH ? 5 : 6) rt_trace_kernel(const DevSce
         bool dmode = scene_diffuse;  // true: inside color_diffuse, false: inside color
         uint32_t depth = 0u;
         uint32_t key = rt_rng_path_key(F.seed, pos, F.frame_index);
-        uint64_t kinds = 0ull;    // two bits per frame, frame d at bits [2d, 2d+1]
+        // two bits per frame, frame d at bits [2d, 2d+1]; without refractive materials every frame of a path has the same
+        // kind (the mode never changes), so the variable is only kept when REFR
+        using Kinds = typename std::conditional<(RDEPTH <= 16), uint32_t, uint64_t>::type;   // 32 bits hold 16 frames
+        Kinds kinds = 0;
         int ray_slot = RT_CNT_RAYS_PRIMARY;
         float rfr[REFR ? RDEPTH : 1][16];
         bool done = false;
@@ -704,10 +707,10 @@ __global__ void __launch_bounds__(256, BVH ? 5 : 6) rt_trace_kernel(const DevSce
                         if (!dmode) {
                             float *fr = s_frames + (size_t)(depth * 4u) * nthr + tid;
                             fr[0] = p.x; fr[nthr] = p.y; fr[2u * nthr] = p.z; fr[3u * nthr] = m.roughness;
-                            kinds = (kinds & ~(3ull << (2u * depth))) | ((uint64_t)FK_REFL << (2u * depth));
+                            if (REFR) kinds = (kinds & ~((Kinds)3 << (2u * depth))) | ((Kinds)FK_REFL << (2u * depth));
                         } else {
                             cnt.add(RT_CNT_COMBINE_REFL);
-                            kinds = (kinds & ~(3ull << (2u * depth))) | ((uint64_t)FK_PASS << (2u * depth));
+                            if (REFR) kinds = (kinds & ~((Kinds)3 << (2u * depth))) | ((Kinds)FK_PASS << (2u * depth));
                         }
                         ro = no; rd = nd; L = p; Cc = Cc * albedo;
                         key = rt_rng_child_key(key, 0u);
@@ -733,14 +736,14 @@ __global__ void __launch_bounds__(256, BVH ? 5 : 6) rt_trace_kernel(const DevSce
                             f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = ldv.x; f[4] = ldv.y; f[5] = ldv.z;
                             f[6] = p.x; f[7] = p.y; f[8] = p.z; f[9] = cchild.x; f[10] = cchild.y; f[11] = cchild.z;
                             f[14] = __uint_as_float(rt_rng_child_key(key, 0u));
-                            kinds = (kinds & ~(3ull << (2u * depth))) | ((uint64_t)FK_REFR1 << (2u * depth));
+                            kinds = (kinds & ~((Kinds)3 << (2u * depth))) | ((Kinds)FK_REFR1 << (2u * depth));
                             ro = fo; rd = fd; Cc = cchild;  // L unchanged: the refraction child gets the parent's light_color
                             key = rt_rng_child_key(key, 1u);
                             dmode = false;                 // the refraction child always runs color()
                             ray_slot = RT_CNT_RAYS_REFRACTION;
                         } else {
                             f[0] = 0.0f; f[1] = 0.0f; f[2] = 0.0f;
-                            kinds = (kinds & ~(3ull << (2u * depth))) | ((uint64_t)FK_REFR2 << (2u * depth));
+                            kinds = (kinds & ~((Kinds)3 << (2u * depth))) | ((Kinds)FK_REFR2 << (2u * depth));
                             ro = lo; rd = ldv; L = p; Cc = cchild;
                             key = rt_rng_child_key(key, 0u);
                             ray_slot = RT_CNT_RAYS_REFLECTION;
@@ -757,7 +760,7 @@ __global__ void __launch_bounds__(256, BVH ? 5 : 6) rt_trace_kernel(const DevSce
             while (have_value) {
                 if (depth == 0u) { done = true; break; }
                 const uint32_t d = depth - 1u;
-                const uint32_t kind = (uint32_t)(kinds >> (2u * d)) & 3u;
+                const uint32_t kind = REFR ? ((uint32_t)(kinds >> (2u * d)) & 3u) : (scene_diffuse ? (uint32_t)FK_PASS : (uint32_t)FK_REFL);
                 if (kind == FK_PASS) { depth = d; continue; }
                 if (kind == FK_REFL) {
                     const float *fr = s_frames + (size_t)(d * 4u) * nthr + tid;
@@ -776,7 +779,7 @@ __global__ void __launch_bounds__(256, BVH ? 5 : 6) rt_trace_kernel(const DevSce
                         key = __float_as_uint(f[14]);
                         dmode = f[15] != 0.0f;
                         f[0] = V.x; f[1] = V.y; f[2] = V.z;
-                        kinds = (kinds & ~(3ull << (2u * d))) | ((uint64_t)FK_REFR2 << (2u * d));
+                        kinds = (kinds & ~((Kinds)3 << (2u * d))) | ((Kinds)FK_REFR2 << (2u * d));
                         ray_slot = RT_CNT_RAYS_REFLECTION;
                         have_value = false;  // descend into the reflection child at the same depth
                     } else {
