@@ -210,3 +210,21 @@ def test_host_load_image_refuses_what_it_cannot_decode_exactly(pkg, tmp_path):
     wide.save(inter)
     with pytest.raises(ValueError, match="bit depth"):
         pkg.load_image(inter)
+
+
+def test_committed_bench_line_carries_the_contract_fields():
+    """The benchmark line kept under profiles/ (printed by bench.py on the GPU box) has the fields the harness reads."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench_default.json")
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["data"] == "synthetic"
+    assert "scene3" in d["config"]["workload"] and d["config"]["width"] == 3840 and d["config"]["height"] == 2160
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["traffic"] > 0 and r["unit"] == "TFLOP/s"
+    # the whole-job rate is the ray count of one step over the step time
+    assert abs(d["value"] - d["config"]["rays_per_step_per_rank"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"]
