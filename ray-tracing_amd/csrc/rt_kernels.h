@@ -833,7 +833,9 @@ RT_DEV float rt_smooth_step(float e0, float e1, float x) {  // :29-32
 // pixel the world ray is fixed, so the kernel computes each leaf's object-space ray once (rm_fill_cache) and keeps it
 // in LDS: the direction per lane (one column per lane), the origin once per workgroup (every primary ray starts at
 // the camera position).  Leaves are numbered in evaluation order, which is the same in every sdfs() call.
-constexpr uint32_t kMarchThreads = 256u;  // workgroup size of the march kernel (compile-time: LDS offsets become immediates)
+// One wavefront per workgroup: march lengths differ widely between tiles, and single-wave workgroups release their slots
+// one by one (measured 1.8 % faster than 256 threads on the 4K ray-marching scene).
+constexpr uint32_t kMarchThreads = 64u;  // workgroup size of the march kernel (compile-time: LDS offsets become immediates)
 struct RayCache {
     float *trd;        // this lane's column: component c of slot s at trd[(s * 3 + c) * kMarchThreads]
     float *tro;        // workgroup-wide: component c of slot s at tro[s * 3 + c]
