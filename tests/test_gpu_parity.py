@@ -614,6 +614,57 @@ def test_random_small_scenes_through_the_linear_scan(pkg, orc, ctx, seed):
 
 
 @pytest.mark.parametrize("seed", list(range(6)))
+def test_random_scenes_through_the_hierarchy(pkg, orc, ctx, seed):
+    """Random scenes of 40-90 bounded objects of every kind plus planes (above the hierarchy threshold), overlapping and
+    rotated, with shadows, glass and textures: the hierarchy traversal (timed and counting variants) gives the linear
+    scan of the oracle bit for bit, ties between equal distances included."""
+    rng = np.random.default_rng(5000 + seed)
+    mats = [make_material(pkg, albedo=tuple(rng.uniform(0.2, 0.9, 3)), roughness=float(rng.uniform(0.2, 1.0)), ambience=0.4,
+                          shininess=float(rng.uniform(3, 120)), specular=float(rng.uniform(0.2, 1.5))) for _ in range(5)]
+    mats.append(make_material(pkg, albedo=(0.9, 0.95, 1.0), kind=pkg.RT_REFRACTIVE, transparency=0.9, refraction_index=1.2, reflectivity=0.1))
+    mats.append(make_material(pkg, albedo=(0.5, 0.5, 0.5), texture=int(rng.integers(0, 4)), roughness=0.7, ambience=0.4))
+    objs = [make_object(pkg, pkg.RT_PLANE, int(rng.integers(0, 5)), normal=(0, 1, 0), point=(0, -0.6, 0), max_dist=(9.0, 9.0), has_max_dist=seed % 2)]
+    n = int(rng.integers(40, 90))
+    for i in range(n):
+        pos = (float(rng.uniform(-5, 5)), float(rng.uniform(-0.3, 2.5)), float(rng.uniform(-7, 2)))
+        rot = tuple(float(a) for a in rng.uniform(-180, 180, 3))
+        m = int(rng.integers(0, 7))
+        kind = int(rng.integers(0, 5))
+        if i > 0 and i % 17 == 0:                     # an exact duplicate of the previous object: equal distances on every ray
+            objs.append(pkg.rt_object.from_buffer_copy(objs[-1]))
+        elif kind == 0:
+            objs.append(make_object(pkg, pkg.RT_SPHERE, m, position=pos, rotation_axis=rot, radius=float(rng.uniform(0.2, 0.9))))
+        elif kind == 1:
+            objs.append(make_object(pkg, pkg.RT_CUBOID, m, position=pos, rotation_axis=rot, dimension=tuple(float(a) for a in rng.uniform(0.15, 0.7, 3))))
+        elif kind == 2:
+            objs.append(make_object(pkg, pkg.RT_CYLINDER, m, position=pos, rotation_axis=rot, radius=0.3, height=1.0))
+        elif kind == 3:
+            objs.append(make_object(pkg, pkg.RT_CONE, m, position=pos, rotation_axis=rot, radius=float(rng.uniform(0.2, 0.6)), height=float(rng.uniform(0.4, 1.2))))
+        else:
+            v1 = np.array(pos)
+            objs.append(make_object(pkg, pkg.RT_TRIANGLE, m, v1=tuple(v1), v2=tuple(v1 + rng.uniform(-1.2, 1.2, 3)), v3=tuple(v1 + rng.uniform(-1.2, 1.2, 3))))
+    lights = [make_light(pkg, pkg.RT_POSITIONAL, (1, 1, 1), (2.0, 6.0, 3.0), 30.0), make_light(pkg, pkg.RT_DIRECTIONAL, (1, 0.9, 0.8), (0.3, -1.0, -0.2), 0.6)]
+    sb = SceneBuilder(pkg, objs, mats, lights, n_textures=4, max_ray_bounces=int(rng.integers(2, 6)), shadow_casting=seed % 2,
+                      ambient_color=(0.05, 0.08, 0.12))
+    cam = pkg.make_camera((float(rng.uniform(-2, 2)), float(rng.uniform(0.8, 3)), float(rng.uniform(4, 8))), (float(rng.uniform(-0.2, 0.2)), -0.2, -1.0), 136, 88)
+    tex = pkg.load_textures()
+    for i, t in enumerate(tex):
+        ctx.set_texture(i, t)
+    ctx.set_scene(sb.desc)
+    ctx.set_camera(cam)
+    rgba, lin, st = gpu_frame(ctx, events=True)
+    assert st["bvh_node"] > 0                                  # the hierarchy was used
+    ref = orc.render(sb.desc, cam, tex, want_counters=True, n_threads=8)
+    assert_parity(rgba, ref["rgba"], lin, ref["accum"], what=f"random hierarchy scene {seed}")
+    cref = dict(zip(pkg.COUNTER_NAMES, ref["counters"]))
+    assert _counters_without_candidate_tests(pkg, st) == _counters_without_candidate_tests(pkg, cref)
+    ctx.reset_accum()
+    ctx.render_device(frame_index=1)
+    assert ctx.stats()["rays_total"] == st["rays_total"]
+    assert np.array_equal(ctx.read_accum().view(np.uint32), lin.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
 def test_random_scenes_in_the_random_number_modes(pkg, orc, ctx, seed):
     """Diffuse path tracing and the roughness-jitter mode on random small scenes (emissive, glass and plain materials),
     three accumulated samples with a fixed seed: accumulator and bytes equal the oracle's after every sample."""
