@@ -4,7 +4,7 @@ WLS=$1; shift
 for r in 1 2; do
 for lib in "$@"; do
   for wl in $WLS; do
-    RT_MI355X_LIB=$PWD/$lib timeout -k 10 120 python3 bench.py --workload $wl --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python3 -c "
+    RT_MI355X_LIB=$PWD/$lib timeout -k 10 120 python3 bench.py --workload $wl ${ABSTEPS:---steps 200 --warmup 20} --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$lib', '$wl', 'ms', d['ms_per_step'], 'Mrays/s', d['value'], 'frac', d['roofline']['frac'])"
   done
