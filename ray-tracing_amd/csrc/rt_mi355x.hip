@@ -452,7 +452,8 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
     const bool events = p->collect_events != 0;
     const uint32_t maxd = S.max_ray_bounces;
     // 256-thread workgroups keep max_ray_bounces * 4 KiB of reflective frames in LDS; deeper recursions use one wave per workgroup
-    const uint32_t threads = S.ray_marching ? kMarchThreads : (maxd <= 8u ? 256u : 64u);
+    // (hierarchy scenes: traversal lengths differ widely between wavefronts, and single-wave workgroups release their slots one by one)
+    const uint32_t threads = S.ray_marching ? kMarchThreads : ((maxd <= 8u && !S.bvh_nodes) ? 256u : 64u);
     const uint32_t waves_per_block = threads / 64u;
     const uint32_t tiles_x = (c->camera.width + 7u) / 8u, tiles_y = (re - rb + 7u) / 8u;
     // 2-D grid: y = tile row, x = group of waves_per_block tile columns
