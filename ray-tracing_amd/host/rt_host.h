@@ -152,8 +152,8 @@ struct CameraEvent {
     Vec2 delta{};
 };
 
-// src/camera.rs:6-126.  ray_directions (the per-pixel table) does not exist here: the kernels
-// generate primary directions from inverse_perspective / inverse_view / position.
+// src/camera.rs:6-126.  ray_directions (the per-pixel table) does not exist here: rt_set_camera builds it on the
+// device from inverse_perspective / inverse_view / position.
 struct Camera {
     size_t width = 800, height = 600;
     float fov = 45.0f, near_ = -1.0f, far_ = -100.0f;

@@ -417,6 +417,43 @@ def test_animated_scene_through_the_renderer_mirror(pkg, orc, name):
     assert not np.array_equal(img[0], img[frames - 1]), "the animation did not move anything"
 
 
+def test_command_line_driver_of_the_host_mirror(pkg, tmp_path):
+    """rt_render_ppm (scene constructors, load_image, with_texture, update function, Renderer::render, PPM out) renders the
+    third frame of the animated textured scene to the bytes rth_render_animation delivers for the same time step."""
+    import subprocess
+    from PIL import Image
+    exe = os.path.join(os.path.dirname(pkg.__file__), "rt_render_ppm")
+    assert os.path.exists(exe), "rt_render_ppm was not built"
+    s = pkg.Scene("scene1")
+    tex = s.textures()
+    paths = []
+    for i, (name, t) in enumerate(zip(pkg.TEXTURE_FILES, tex)):
+        if name.endswith(".png"):
+            paths.append(os.path.join(pkg.TEXTURE_DIR, name))          # decoded by the C++ loader
+        else:                                                            # JPEG: decoded here, handed over as PPM
+            path = str(tmp_path / f"tex{i}.ppm")
+            with open(path, "wb") as fh:
+                fh.write(b"P6\n%d %d\n255\n" % (t.shape[1], t.shape[0]) + t.tobytes())
+            paths.append(path)
+    w, h, frames = 128, 96, 3
+    out = str(tmp_path / "frame.ppm")
+    r = subprocess.run([exe, "scene1", str(w), str(h), str(frames), out] + paths, capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stderr
+    assert "1 scene upload(s), 2 object update(s)" in r.stdout
+    got = np.asarray(Image.open(out).convert("RGB"), dtype=np.uint8)
+    tw = (C.c_uint32 * 4)(*[t.shape[1] for t in tex])
+    th = (C.c_uint32 * 4)(*[t.shape[0] for t in tex])
+    tp = (C.c_void_p * 4)(*[t.ctypes.data for t in tex])
+    img = np.zeros((frames, h, w, 4), dtype=np.uint8)
+    full, part = C.c_uint64(), C.c_uint64()
+    err = C.create_string_buffer(256)
+    st = pkg.host().rth_render_animation(s.handle(), w, h, frames, 1.0 / 60.0, 4, tw, th, tp, 0, img.ctypes.data, None, C.byref(full), C.byref(part), err, 256)
+    assert st == 0, err.value
+    assert np.array_equal(got, img[frames - 1][..., :3])
+    bad = subprocess.run([exe, "nowhere", "8", "8", "1", out], capture_output=True, text=True, timeout=100)
+    assert bad.returncode == 2 and "unknown scene" in bad.stderr
+
+
 @pytest.mark.parametrize("name", ["scene3", "scene1", "tex4", "scene4"])
 def test_full_size_4k_properties(pkg, orc, ctx, name):
     """3840x2160 (the benchmark size): determinism, variant agreement, and oracle parity on sampled rows."""

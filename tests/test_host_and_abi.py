@@ -228,3 +228,17 @@ def test_committed_bench_line_carries_the_contract_fields():
     assert abs(d["value"] - d["config"]["rays_per_step_per_rank"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"]
+
+
+def test_command_line_driver_is_built_and_checks_its_arguments(pkg):
+    """rt_render_ppm (the host mirror's frame loop as a program) exists after the build and rejects bad arguments before
+    it touches a device."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.__file__), "rt_render_ppm")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "usage" in r.stderr
+    r = subprocess.run([exe, "nowhere", "8", "8", "1", os.devnull], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "unknown scene" in r.stderr
+    r = subprocess.run([exe, "scene3", "0", "8", "1", os.devnull], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "positive" in r.stderr
