@@ -53,6 +53,11 @@ def main() -> None:
     ap.add_argument("--shard", default=None, choices=["frames", "rows", "samples"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    # Libraries loaded below write banners to file descriptor 1 (RCCL prints its version block there).  The one JSON line is
+    # the only thing that may reach the real stdout: keep a private handle to it and point descriptor 1 at stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -227,7 +232,8 @@ def main() -> None:
             out["config"]["sdf_list_evals_per_s"] = round(st["sdfs_call"] / (kernel_ms * 1e-3), 1)
         if world == 1 and not args.no_cpu_baseline:   # a reported baseline of the single-GPU line only
             out["cpu_baseline"] = cpu_baseline(pkg, scene, width, height, accumulate)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if use_dist:
         dist.barrier()
