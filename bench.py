@@ -31,6 +31,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X: 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz (packed FP32 FMA)
 
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E
 CLOCK_PREWARM_S = 0.1   # untimed rendering before the warm-up steps (see main)
 
 WORKLOADS = {
@@ -227,6 +228,12 @@ def main() -> None:
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
                          "note": "FP32 vector (VALU) roofline: this path has no dense contraction, so no MFMA"},
         }
+        traffic = out["roofline"]["traffic"]
+        if traffic:
+            # the secondary bound: measured HBM bytes of one launch (direction table read, accumulator and RGBA8 written) over
+            # the launch time, against the 8 TB/s HBM3E peak
+            gbps = traffic / (kernel_ms * 1e-3) / 1e9
+            out["roofline"]["hbm_view"] = {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4)}
         if scene.desc.ray_marching:
             # one sdfs() call evaluates the whole SDF list once (src/ray_marching/ray_marching.rs:24-107)
             out["config"]["sdf_list_evals_per_s"] = round(st["sdfs_call"] / (kernel_ms * 1e-3), 1)
