@@ -631,11 +631,12 @@ enum { FK_REFL = 0, FK_REFR1 = 1, FK_REFR2 = 2, FK_PASS = 3 };
 //   BVH    : closest hits go through the bounding-volume hierarchy (scenes with many objects)
 //   dynamic LDS: max_ray_bounces * 4 * blockDim.x floats (reflective frames, one column per lane)
 // ------------------------------------------------------------------------------------------------
-// second launch bound = waves per SIMD: keeps the allocation at <= 80 VGPRs (6 waves per SIMD; measured: 5 waves 4 % slower,
-// 7 waves equal, 8 waves 12 % slower from spills; the hierarchy variants need the 96 registers of 5 waves: 5 % faster than 6).
+// second launch bound = waves per SIMD.  Plain variant: 7 waves (72 VGPRs, 16 bytes of spills; measured against 6 waves:
+// tex4 -2.6 %, scene2 -2.5 %, scene3 -0.3 %; 8 waves spill heavily, +50 %).  Variants with refractive frames: 6 waves
+// (80 VGPRs; 5 or 4 waves measured slower).  Hierarchy variants: the 96 registers of 5 waves (5 % faster than 6).
 // The march kernel below fits 8 waves per SIMD (64 VGPRs).
 template <bool EVENTS, bool REFR, int RDEPTH, bool BVH>
-__global__ void __launch_bounds__(256, BVH ? 5 : 6) rt_trace_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
+__global__ void __launch_bounds__(256, BVH ? 5 : (REFR ? 6 : 7)) rt_trace_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
     extern __shared__ float s_frames[];
     __shared__ uint32_t s_cnt[(EVENTS ? RT_CNT_COUNT : 0) + 1];
     __shared__ __attribute__((aligned(16))) double s_pow[RT_POW_LDS_DOUBLES];
