@@ -1,26 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the rendering hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--shard rows|samples|frames]
 
 A step is one frame of the hot path (camera rays -> closest hit -> shading -> bounces -> accumulate/pack) over
 one synthetic camera/scene already resident in HBM.  The default workload is BASELINE.json's configs[1]: the
 reference's default plane+sphere scene (src/bin/scene3.rs) at 3840x2160, 1 spp, max 5 bounces.  The metric is
 Mrays/s, a ray being one trace_ray or march_ray invocation (primary, reflection, refraction, shadow).
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Frames are independent units, so each rank
-renders its own frames of the sequence with no collective in the data path ("weak": per-GPU work is fixed); the
-timing is barrier + synchronize on both sides and the maximum over ranks.  `--shard rows` instead splits every
-frame into row bands (one per rank), and `--shard samples` splits the samples of an accumulated frame and
-all-reduces the accumulators once per step.
-
-Rank 0 prints one JSON line.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Started without WORLD_SIZE in the environment,
+this script starts the N ranks itself, as fresh child processes, before anything touches a GPU; under
+torch.distributed.run it is one of the ranks.  The frame is split the way the reference splits it into chunks
+(src/renderer.rs:104-143):
+  rows     (1-spp workloads) every rank renders every N-th 8-row tile row of each frame; one all-gather of RGBA8 tile
+           rows per frame leaves the whole frame on every rank.
+  samples  (the 64-spp workload) every rank renders its share of the sample indices into its own accumulator; one
+           reduce-scatter(sum) of the accumulators, resolve of the owned rows, one all-gather of RGBA8 bands per frame.
+  frames   (opt-in) whole frames of a sequence per rank, no collective.
+The timing is barrier + synchronize on both sides and the maximum over ranks.  Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,14 +40,37 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E
 CLOCK_PREWARM_S = 0.1   # untimed rendering before the warm-up steps (see main)
 
 WORKLOADS = {
-    # name: (scene, width, height, max_ray_bounces or None, accumulate, samples per step, default sharding, description)
-    "scene3_4k": ("scene3", 3840, 2160, 5, False, 1, "frames", "reference default scene (plane + sphere, 2 lights, shadows), 3840x2160, 1 spp, max 5 bounces"),
-    "scene1_4k": ("scene1", 3840, 2160, 5, False, 1, "frames", "all-primitives textured scene, 3840x2160, 1 spp, max 5 bounces"),
-    "tex4_4k": ("tex4", 3840, 2160, 5, False, 1, "frames", "four textured spheres over a chess plane, 3840x2160, 1 spp, max 5 bounces"),
-    "scene4_4k": ("scene4", 3840, 2160, None, False, 1, "frames", "ray-marching SDF scene, 3840x2160, 255 max march steps"),
-    "scene2_4k": ("scene2", 3840, 2160, 5, True, 1, "frames", "diffuse emissive path tracing with accumulation, 3840x2160"),
+    # name: (scene, width, height, max_ray_bounces or None, accumulate, samples per step, sharding for N > 1, description)
+    "scene3_4k": ("scene3", 3840, 2160, 5, False, 1, "rows", "reference default scene (plane + sphere, 2 lights, shadows), 3840x2160, 1 spp, max 5 bounces"),
+    "scene1_4k": ("scene1", 3840, 2160, 5, False, 1, "rows", "all-primitives textured scene, 3840x2160, 1 spp, max 5 bounces"),
+    "tex4_4k": ("tex4", 3840, 2160, 5, False, 1, "rows", "four textured spheres over a chess plane, 3840x2160, 1 spp, max 5 bounces"),
+    "scene4_4k": ("scene4", 3840, 2160, None, False, 1, "rows", "ray-marching SDF scene, 3840x2160, 255 max march steps"),
+    "scene2_4k": ("scene2", 3840, 2160, 5, True, 1, "rows", "diffuse emissive path tracing with accumulation, 3840x2160"),
     "spheres10k_8k": ("spheres10k", 7680, 4320, 5, True, 64, "samples", "10 000 diffuse spheres, 7680x4320, 64 spp accumulated per frame"),
+    "spheres10k_4k": ("spheres10k", 3840, 2160, 5, True, 1, "rows", "10 000 diffuse spheres, 3840x2160, 1 spp per step (accumulating)"),
+    "scene3_800x600": ("scene3", 800, 600, None, False, 1, "rows", "reference default scene at its default viewport (800x600, max 4 bounces): BASELINE config 1"),
 }
+
+
+def spawn_ranks(n: int) -> int:
+    """Starts the N ranks of a single-node run as fresh child processes of this (GPU-free) parent and waits for them.
+    Rank 0 inherits stdout, so its JSON line is this command's output.  Returns the worst exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
 
 
 def main() -> None:
@@ -54,26 +82,35 @@ def main() -> None:
     ap.add_argument("--shard", default=None, choices=["frames", "rows", "samples"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # nothing in this process has touched a GPU (or imported torch) yet: the ranks are fresh processes
+        sys.exit(spawn_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (or leave WORLD_SIZE unset and let bench.py start them)")
     # Libraries loaded below write banners to file descriptor 1 (RCCL prints its version block there).  The one JSON line is
     # the only thing that may reach the real stdout: keep a private handle to it and point descriptor 1 at stderr.
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import numpy as np
     import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # one rank per GPU; RT_BENCH_BACKEND=gloo rehearses the multi-process launch of the default (frames) sharding on a
-    # box with fewer GPUs than ranks (ranks then share devices round-robin; gloo's collectives on device tensors are
-    # not what the rows / samples modes are written for)
+    # one rank per GPU over RCCL.  RT_BENCH_BACKEND=gloo rehearses the multi-process launch on a box with fewer GPUs than
+    # ranks: ranks then share devices round-robin and the collectives are staged through host memory.
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
-    device_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
-    # RT_BENCH_FORCE_DIST=1 makes a single rank go through the process group as well (its barrier and reductions), which
-    # rehearses the RCCL calls of the multi-GPU launch on a one-GPU box
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        sys.exit(f"bench.py: {world} ranks but {n_dev} GPU(s) visible; RT_BENCH_BACKEND=gloo rehearses the launch on fewer GPUs")
+    device_index = local_rank if backend == "nccl" else local_rank % max(1, n_dev)
+    # RT_BENCH_FORCE_DIST=1 makes a single rank go through the process group as well, which rehearses the RCCL calls of
+    # the multi-GPU launch on a one-GPU box
     use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    dist = None
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -87,84 +124,92 @@ def main() -> None:
     torch.cuda.set_device(device_index)
 
     pkg = graft.load_package()
-    scene_name, width, height, bounces, accumulate, spp, default_shard, description = WORKLOADS[args.workload]
+    scene_name, width, height, bounces, accumulate, spp, multi_shard, description = WORKLOADS[args.workload]
     # a 4K frame takes 0.1-1 ms: 1000 timed frames take at most a second
     if args.steps is None:
         args.steps = 1000 if spp == 1 else 5
     if args.warmup is None:
         args.warmup = 20 if spp == 1 else 1
-    shard = args.shard or default_shard
+    shard = args.shard or (multi_shard if use_dist else "none")
+    if shard == "samples" and spp == 1:
+        sys.exit("bench.py: --shard samples needs a multi-sample workload (spheres10k_8k)")
     scene = pkg.Scene(scene_name)
     if bounces is not None:
         scene.desc.max_ray_bounces = bounces
     ctx = pkg.Context(device_index)
     ctx.load(scene, width, height)
 
-    rgba = torch.zeros((height, width, 4), dtype=torch.uint8, device="cuda")
-    accum = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
+    # every buffer a step touches exists before the timed loop: frame, accumulator, and the collectives' send/receive blocks
+    xch = pkg.FrameExchange(dist, height, width, rank, world, device="cuda", backend=backend, force_collectives=use_dist)
+    rgba, accum = xch.frame, xch.accum
     stream = torch.cuda.current_stream()
     sh = stream.cuda_stream
-    my_rows = pkg.shard_rows(height, rank, world)
+    rows_arg = xch.render_rows() if (shard == "rows" and xch.collectives) else None
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def render(sample_index: int, rows=None, acc: bool = accumulate) -> None:
+    def render(sample_index: int, acc: bool = accumulate, rows=rows_arg, events: bool = False) -> None:
         # the timed region is bracketed by this script's own events, so the library's per-launch timing events are off
-        ctx.render_device(frame_index=sample_index if acc else 1, accumulate=acc, seed=0x5EED, rows=rows,
-                          d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh, no_timing=True)
+        ctx.render_device(frame_index=sample_index if acc else 1, accumulate=acc, seed=0x5EED,
+                          rows=(rows[0], rows[1]) if rows else None, tile_row_stride=rows[2] if rows else 0,
+                          d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh, no_timing=not events, collect_events=events)
 
-    def step(i: int) -> None:
-        if shard == "frames":
-            # whole frames of a sequence go to different ranks: rank r renders frames r, r + world, ...; no collective
-            for k in range(spp):
-                render(1 + (i * world + rank) * spp + k)
-        elif shard == "rows":
-            # one frame per step, one row band per rank; the bands are all-gathered so that every rank holds the frame
-            for k in range(spp):
-                render(1 + i * spp + k, rows=my_rows if world > 1 else None)
-            if world > 1:
-                rgba.copy_(pkg.gather_row_bands(dist, rgba, height, rank, world))
-        else:
-            # the spp samples of one accumulated frame are split by sample index; a reduce-scatter leaves each rank with
-            # the summed rows it owns, which it resolves (divide, clamp, pack); the RGBA8 bands are then all-gathered
-            accum.zero_()
-            for idx in pkg.shard_samples(spp, rank, world, 1 + i * spp):
-                render(idx, acc=True)
-            rb, re, band = pkg.reduce_scatter_accumulators(dist if world > 1 else None, accum, rank, world)
-            if band.data_ptr() == accum.data_ptr() + rb * width * 16:
-                # all-reduce fallback or single GPU: the band is a slice of the full accumulator
-                ctx.resolve_device(spp, rows=(rb, re), d_accum=accum.data_ptr(), d_rgba8=rgba.data_ptr(), stream=sh)
-                if world > 1:
-                    rgba.copy_(pkg.gather_row_bands(dist, rgba, height, rank, world))
-            else:
-                # the band is its own tensor: resolve it as rows [0, re - rb) straight into this rank's rows of the frame
-                ctx.resolve_device(spp, rows=(0, re - rb), d_accum=band.data_ptr(), d_rgba8=rgba.data_ptr() + rb * width * 4, stream=sh)
-                pkg.gather_equal_bands(dist, rgba[rb:re].clone(), rgba)   # the send buffer must not alias the receive buffer
-
-    def rays_of_step(i: int) -> int:
-        """Rays this rank traces in step i (untimed pass: one stats read-back per render)."""
-        total = 0
+    def sample_ids(i: int):
         if shard == "samples":
-            ids = pkg.shard_samples(spp, rank, world, 1 + i * spp)
-        elif shard == "frames":
-            ids = [1 + (i * world + rank) * spp + k for k in range(spp)]
+            return pkg.shard_samples(spp, rank, world, 1 + i * spp)
+        if shard == "frames":
+            return [1 + (i * world + rank) * spp + k for k in range(spp)]
+        return [1 + i * spp + k for k in range(spp)]
+
+    kernel_events, exchange_events = [], []
+
+    def step(i: int, timed: bool = False) -> None:
+        # per-step events only where a step has collectives to separate from the render launches (an event pair costs
+        # several microseconds on the stream: too much for a 0.1 ms frame); otherwise one pair brackets the timed loop
+        timed = timed and xch.collectives and shard in ("rows", "samples")
+        if timed:
+            k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            k0.record(stream)
+        if shard == "samples":
+            accum.zero_()
+        for idx in sample_ids(i):
+            render(idx, acc=True if shard == "samples" else accumulate)
+        if timed:
+            k1.record(stream)
+            kernel_events.append((k0, k1))
+        if shard in ("none", "frames") or not xch.collectives:
+            return
+        if shard == "rows":
+            xch.gather_interleaved()
         else:
-            ids = [1 + i * spp + k for k in range(spp)]
-        for idx in ids:
-            render(idx, rows=my_rows if (shard == "rows" and world > 1) else None, acc=accumulate or shard == "samples")
-            total += ctx.stats()["rays_total"]
-        return total
+            # a reduce-scatter leaves each rank with the summed rows it owns; it resolves them (divide, clamp, pack) and the
+            # RGBA8 bands are all-gathered
+            rb, re, band = xch.sum_accumulators()
+            if xch.reduce_scatter:
+                ctx.resolve_device(spp, rows=(0, re - rb), d_accum=band.data_ptr(), d_rgba8=xch.band_rgba.data_ptr(), stream=sh)
+            else:
+                ctx.resolve_device(spp, rows=(rb, re), d_accum=accum.data_ptr(), d_rgba8=rgba.data_ptr(), stream=sh)
+            xch.gather_bands(rb, re)
+        if timed:
+            x1 = torch.cuda.Event(enable_timing=True)
+            x1.record(stream)
+            exchange_events.append((k1, x1))
 
     # The GPU raises its clock over the first ~50 ms of sustained work (measured: a scene3 frame goes from 0.125 ms to a steady
     # 0.104 ms over the first 500 frames).  Render untimed frames for that long before the warm-up steps, so that the timed
-    # steps see the steady clock whatever --warmup says.
-    # (Time-based, so only where steps have no collective: ranks may render different numbers of pre-warm frames.)
-    t_pre = time.perf_counter()
-    while (shard == "frames" or world == 1) and time.perf_counter() - t_pre < CLOCK_PREWARM_S:
-        for _ in range(8 if spp == 1 else 1):
+    # steps see the steady clock whatever --warmup says.  With collectives in the step every rank must run the same number of
+    # steps, so there the pre-warm is a fixed count.
+    if not xch.collectives or shard in ("none", "frames"):
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < CLOCK_PREWARM_S:
+            for _ in range(8 if spp == 1 else 1):
+                step(0)
+            torch.cuda.synchronize()
+    else:
+        for _ in range(200 if spp == 1 else 1):
             step(0)
         torch.cuda.synchronize()
     for i in range(args.warmup):
@@ -174,34 +219,43 @@ def main() -> None:
     t0 = time.perf_counter()
     ev0.record(stream)
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(args.warmup + i, timed=True)
     ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    launches_per_step = len(pkg.shard_samples(spp, rank, world)) if shard == "samples" else spp
-    # average launch duration of the dominant kernel on the launch stream (launches are back to back; at 1 spp without
-    # collectives this is the whole step)
-    kernel_ms = ev0.elapsed_time(ev1) / (args.steps * launches_per_step)
+    launches_per_step = len(sample_ids(0))
+    # average launch duration of the render kernel(s), from events on the launch stream: around each step's render launches
+    # when the step also has collectives, around the whole timed loop (launches back to back) otherwise
+    if kernel_events:
+        kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / (args.steps * launches_per_step)
+    else:
+        kernel_ms = ev0.elapsed_time(ev1) / (args.steps * launches_per_step)
+    exchange_ms = sum(a.elapsed_time(b) for a, b in exchange_events) / args.steps if exchange_events else 0.0
     # rays per step: deterministic scenes trace the same rays every frame; random modes vary by < 0.1 % between sample sets,
-    # so the count of the first timed step's sample set stands for every step
-    rays_rank = rays_of_step(args.warmup)
+    # so the count of the first timed step's sample set stands for every step (untimed pass: one stats read-back per render)
+    rays_rank = 0
+    for idx in sample_ids(args.warmup):
+        render(idx, acc=True if shard == "samples" else accumulate)
+        rays_rank += ctx.stats()["rays_total"]
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     r = torch.tensor([float(rays_rank)], dtype=torch.float64, device="cuda")
     if use_dist:
+        if xch.staged:
+            t, r = t.cpu(), r.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
     elapsed_max = float(t.item())
     rays_per_step_all = float(r.item())
 
     if rank == 0:
-        # algorithmic FLOPs of one frame: event counts of a (slower, untimed) counting render times the per-event constants
-        ctx.render_device(frame_index=1, accumulate=False, seed=0x5EED, rows=my_rows if (shard == "rows" and world > 1) else None,
-                          collect_events=True, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh)
+        # algorithmic FLOPs of one launch: event counts of a (slower, untimed) counting render times the per-event constants
+        render(1, acc=False, events=True)
         st = ctx.stats()
         flops = pkg.algorithmic_flops(st)
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         value = rays_per_step_all * args.steps / elapsed_max / 1e6
+        traffic, traffic_note = measured_traffic(args.workload, pkg.LIB_PATH)
         out = {
             "metric": "Mrays/sec (primary+secondary) and frame ms at 4K",
             "value": round(value, 2),
@@ -218,9 +272,13 @@ def main() -> None:
             "config": {"workload": f"{args.workload}: {description}", "width": width, "height": height,
                        "max_ray_bounces": int(scene.desc.max_ray_bounces), "samples_per_step": spp,
                        "rays_per_step_per_rank": int(rays_rank), "sharding": shard, "clock_prewarm_ms": int(CLOCK_PREWARM_S * 1e3),
+                       "ranks": world, "backend": backend if use_dist else "none", "exchange_ms_per_step": round(exchange_ms, 4),
+                       "collective": ("none" if shard in ("none", "frames") or not xch.collectives else
+                                      "all_gather(rgba8 tile rows)" if shard == "rows" else
+                                      ("reduce_scatter(f32 accum) + all_gather(rgba8 bands)" if xch.reduce_scatter else "all_reduce(f32 accum) + all_gather(rgba8 bands)")),
                        "parallelism": f"{shard}-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": measured_traffic(args.workload),
+                         "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": traffic,
                          # the 157.3 TFLOP/s peak is one FMA (2 flops) per lane every 2 cycles; bit-exact parity keeps multiplies
                          # and adds unfused, so one flop per lane-instruction (half of it) bounds this code
                          "frac_of_unfused_peak": round(achieved / (FP32_VALU_PEAK_TFLOPS / 2.0), 5),
@@ -228,12 +286,15 @@ def main() -> None:
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
                          "note": "FP32 vector (VALU) roofline: this path has no dense contraction, so no MFMA"},
         }
-        traffic = out["roofline"]["traffic"]
+        if traffic_note:
+            out["roofline"]["traffic_note"] = traffic_note
         if traffic:
-            # the secondary bound: measured HBM bytes of one launch (direction table read, accumulator and RGBA8 written) over
-            # the launch time, against the 8 TB/s HBM3E peak
+            # the secondary bound: measured HBM bytes of one launch over the launch time, against the 8 TB/s HBM3E peak, and
+            # against the bytes the frame has to move at the least (4 B RGBA8 per pixel; 36 B when accumulating)
             gbps = traffic / (kernel_ms * 1e-3) / 1e9
-            out["roofline"]["hbm_view"] = {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4)}
+            alg = width * height * (36 if accumulate else 4)
+            out["roofline"]["hbm_view"] = {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                                           "algorithmic_bytes": alg, "traffic_over_algorithmic": round(traffic / alg, 2)}
         if scene.desc.ray_marching:
             # one sdfs() call evaluates the whole SDF list once (src/ray_marching/ray_marching.rs:24-107)
             out["config"]["sdf_list_evals_per_s"] = round(st["sdfs_call"] / (kernel_ms * 1e-3), 1)
@@ -247,15 +308,30 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def measured_traffic(workload: str):
-    """HBM bytes per launch of the workload's render kernel from the committed PMC passes (FETCH_SIZE and WRITE_SIZE in
-    separate rocprofv3 runs, read side doubled for gfx950), or None when the workload has not been profiled."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+def file_sha256(path: str) -> str:
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for block in iter(lambda: fh.read(1 << 20), b""):
+            h.update(block)
+    return h.hexdigest()
+
+
+def measured_traffic(workload: str, lib_path: str):
+    """(HBM bytes per launch, note).  The bytes come from the committed PMC passes (FETCH_SIZE and WRITE_SIZE in separate
+    rocprofv3 runs, read side doubled for gfx950; tools/profile.sh + tools/update_hbm_traffic.py refresh them) and are
+    only reported when they were measured on the very library file that is running now (its sha256 is stored with them):
+    otherwise None and a note, because kernels change and a stale constant would pass for a measurement."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as fh:
-            return json.load(fh).get(workload, {}).get("bytes_per_launch")
+            entry = json.load(fh).get(workload)
     except (OSError, ValueError):
-        return None
+        entry = None
+    if not entry:
+        return None, "no PMC traffic measurement committed for this workload"
+    if entry.get("lib_sha256") != file_sha256(lib_path):
+        return None, "the committed PMC traffic was measured on a different build of librt_mi355x.so (tools/profile.sh refreshes it)"
+    return entry.get("bytes_per_launch"), None
 
 
 def cpu_baseline(pkg, scene, width, height, accumulate) -> dict:

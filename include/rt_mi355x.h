@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 typedef struct rt_ctx rt_ctx;
 
@@ -210,6 +210,11 @@ typedef struct rt_render_params {
     int32_t no_timing;       /* 1: do not bracket the launch with timing events (about 6 us per launch on the
                               * stream); rt_stats.last_kernel_ms then reads 0 for it                   */
     uint64_t seed;           /* keys the counter-based generator that stands in for ThreadRng        */
+    uint32_t tile_row_stride; /* 0 or 1: every row of [row_begin, row_end).  N > 1: only the 8-row bands that start at
+                              * row_begin, row_begin + 8 N, row_begin + 16 N, ... (row_begin a multiple of 8): the
+                              * interleaved share of one of N GPUs, the counterpart of the reference's chunk list
+                              * dealt round-robin to workers (src/renderer.rs:104-110)                    */
+    uint32_t reserved;
 } rt_render_params;
 
 /* Creates a context bound to HIP device `device_id` (one context per GPU; one process per GPU

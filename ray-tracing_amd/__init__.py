@@ -118,7 +118,8 @@ class rt_stats(C.Structure):
 
 class rt_render_params(C.Structure):
     _fields_ = [("frame_index", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("accumulate", C.c_int32),
-                ("collect_events", C.c_int32), ("no_timing", C.c_int32), ("seed", C.c_uint64)]
+                ("collect_events", C.c_int32), ("no_timing", C.c_int32), ("seed", C.c_uint64),
+                ("tile_row_stride", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # every symbol include/rt_mi355x.h declares
@@ -360,10 +361,11 @@ class Context:
 
     def render_device(self, frame_index: int = 1, accumulate: bool = False, seed: int = 0x5EED, rows: Optional[tuple] = None,
                       collect_events: bool = False, d_rgba8: int = 0, d_accum: int = 0, stream: Optional[int] = None,
-                      no_timing: bool = False):
+                      no_timing: bool = False, noalloc: bool = False, tile_row_stride: int = 0):
         """rt_render_device: asynchronous launch into device buffers (0 = the context's own).
 
-        `stream` is a hipStream_t handle used as is (0 is HIP's default stream); None selects the context's own stream."""
+        `stream` is a hipStream_t handle used as is (0 is HIP's default stream); None selects the context's own stream.
+        `noalloc` calls rt_render_device_noalloc instead (same frame, counter rows in the library's fixed device array)."""
         p = rt_render_params()
         p.frame_index = frame_index
         p.accumulate = int(accumulate)
@@ -372,10 +374,12 @@ class Context:
         p.seed = seed
         if rows is not None:
             p.row_begin, p.row_end = rows
+        p.tile_row_stride = tile_row_stride
         if stream is None:
             stream = int(self._l.rt_context_stream(self._ctx) or 0)
-        self._check(self._l.rt_render_device(self._ctx, C.byref(p), C.c_void_p(d_rgba8 or None), C.c_void_p(d_accum or None),
-                                             C.c_void_p(stream or None)), "rt_render_device")
+        fn = self._l.rt_render_device
+        self._check(fn(self._ctx, C.byref(p), C.c_void_p(d_rgba8 or None), C.c_void_p(d_accum or None), C.c_void_p(stream or None)),
+                    "rt_render_device_noalloc" if noalloc else "rt_render_device")
 
     def resolve_device(self, sample_count: int, rows: Optional[tuple] = None, d_accum: int = 0, d_rgba8: int = 0, stream: Optional[int] = None):
         """rt_resolve_device: accumulated / sample_count -> clamp -> RGBA8 (after an external all-reduce of accumulators)."""
@@ -421,5 +425,5 @@ class Context:
             pass
 
 
-from .sharding import (equal_row_bands, gather_equal_bands, gather_row_bands, reduce_scatter_accumulators,  # noqa: E402,F401
+from .sharding import (FrameExchange, equal_row_bands, gather_row_bands, interleaved_tile_rows,  # noqa: E402,F401
                        render_sample_sharded, shard_rows, shard_samples)

@@ -94,6 +94,7 @@ struct DevCamera {
 struct DevFrame {
     uint32_t frame_index;
     uint32_t row_begin, row_end;
+    uint32_t tile_row_step;  // rows between the starts of consecutive tile rows of this launch: 8, or 8 N for an interleaved share
     uint32_t leaf_slots;  // march kernel: object-space rays cached in LDS (0: none)
     int32_t accumulate;
     uint64_t seed;

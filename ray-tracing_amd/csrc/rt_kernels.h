@@ -619,7 +619,7 @@ RT_DEV bool lane_pixel(const DevCamera &C, const DevFrame &F, uint32_t &x, uint3
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t tx = blockIdx.x * (blockDim.x >> 6) + wave, ty = gridDim.y - 1u - blockIdx.y;
     x = tx * 8u + (lane & 7u);
-    y = F.row_begin + ty * 8u + (lane >> 3);
+    y = F.row_begin + ty * F.tile_row_step + (lane >> 3);
     return x < C.width && y < F.row_end;
 }
 enum { FK_REFL = 0, FK_REFR1 = 1, FK_REFR2 = 2, FK_PASS = 3 };

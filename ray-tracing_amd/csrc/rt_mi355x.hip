@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -26,6 +27,32 @@ namespace {
 constexpr uint32_t kMaxTextures = 64;
 constexpr uint32_t kMaxBounces = 32;  // capacity of the per-lane frame storage
 constexpr uint32_t kMaxCompositeDepth = 2;
+
+// Counter rows of rt_render_device_noalloc: one row per workgroup of a launch.  A file-scope device array instead of a
+// hipMalloc'd block, so that the entry point never allocates; every GPU the library runs on holds its own 4 MiB copy until
+// the process ends.  Host code never uses the array's name as an address: the per-device address comes from
+// hipGetSymbolAddress (scratch_for_device) and travels to the kernels as an ordinary pointer argument.
+constexpr size_t kNoAllocCounterWords = (size_t)1 << 20;
+static __device__ __align__(256) uint32_t scratch[kNoAllocCounterWords];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+uint32_t *g_scratch_ptr[kMaxDevices] = {};
+
+// Address of `scratch` on `device`, which must be the current device.  Looked up once per device.
+hipError_t scratch_for_device(int device, uint32_t **out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = (uint32_t *)p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 template <typename T>
 struct DevBuf {
@@ -70,6 +97,8 @@ struct rt_ctx {
     DevBuf<float> accum;
     DevBuf<float> ray_dirs;   // Camera.ray_directions: 3 floats per pixel
     DevBuf<uint32_t> counters;
+    uint32_t *static_counters = nullptr;       // this device's copy of the file-scope `scratch` array (rt_render_device_noalloc)
+    const uint32_t *last_counters = nullptr;   // counter table the last render wrote
     std::vector<uint32_t> h_counters;
     uint32_t last_blocks = 0, last_ncnt = 0;
     bool kernel_timed = false;           // the last launch was bracketed by ev0 / ev1
@@ -231,7 +260,10 @@ int32_t rt_create(int32_t device_id, rt_ctx **out) {
         rt_destroy(c);
         return RT_ERR_DEVICE;
     }
-    (void)hipMemset(c->textures.ptr, 0, kMaxTextures * sizeof(DevTexture));
+    if (hipMemset(c->textures.ptr, 0, kMaxTextures * sizeof(DevTexture)) != hipSuccess || scratch_for_device(device_id, &c->static_counters) != hipSuccess) {
+        rt_destroy(c);
+        return RT_ERR_DEVICE;
+    }
     *out = c;
     return RT_OK;
 }
@@ -432,7 +464,13 @@ int32_t rt_reset_accum(rt_ctx *c) {
     return RT_OK;
 }
 
-int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d_accum, void *stream) {
+}  // extern "C"
+
+namespace {
+
+// One frame into device buffers.  `noalloc`: the launch's counter rows go to the file-scope `scratch` array instead of a
+// block grown with hipMalloc, and launches that would need more than it holds are refused.
+int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d_accum, void *stream, bool noalloc) {
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!p) return fail(c, RT_ERR_INVALID_ARGUMENT, "params is null");
     if (!c->has_scene || !c->has_camera) return fail(c, RT_ERR_STATE, "scene or camera not set");
@@ -440,6 +478,9 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
     uint32_t rb = p->row_begin, re = p->row_end;
     if (rb == 0 && re == 0) re = c->camera.height;
     if (re > c->camera.height || rb >= re) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad row range");
+    const uint32_t stride = p->tile_row_stride ? p->tile_row_stride : 1u;
+    if (stride > 1u && (rb % 8u) != 0u) return fail(c, RT_ERR_INVALID_ARGUMENT, "row_begin must be a multiple of 8 when tile_row_stride > 1");
+    if (stride > 4096u) return fail(c, RT_ERR_INVALID_ARGUMENT, "tile_row_stride above 4096");
     for (size_t i = 0; i < c->mat_texture.size(); i++) {
         int32_t t = c->mat_texture[i];
         if (t >= 0 && !c->h_textures[t].texels) return fail(c, RT_ERR_STATE, "material " + std::to_string(i) + " uses texture " + std::to_string(t) + " which was never set");
@@ -455,20 +496,29 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
     // (hierarchy scenes: traversal lengths differ widely between wavefronts, and single-wave workgroups release their slots one by one)
     const uint32_t threads = S.ray_marching ? kMarchThreads : ((maxd <= 8u && !S.bvh_nodes) ? 256u : 64u);
     const uint32_t waves_per_block = threads / 64u;
-    const uint32_t tiles_x = (c->camera.width + 7u) / 8u, tiles_y = (re - rb + 7u) / 8u;
+    // tile rows of this launch: every stride-th 8-row band of [rb, re)
+    const uint32_t tiles_x = (c->camera.width + 7u) / 8u, tiles_y = ((re - rb + 7u) / 8u + stride - 1u) / stride;
     // 2-D grid: y = tile row, x = group of waves_per_block tile columns
     const dim3 grid((tiles_x + waves_per_block - 1u) / waves_per_block, tiles_y);
     const uint32_t blocks = grid.x * grid.y;
     const uint64_t n_waves = (uint64_t)blocks * waves_per_block;  // diagnostic builds size their table by it
     (void)n_waves;
     const uint32_t ncnt = (events ? (uint32_t)RT_CNT_COUNT : 0u) + 1u;
-    RT_HIP(c, c->counters.ensure((size_t)blocks * ncnt));
+    uint32_t *counters = nullptr;
+    if (noalloc) {
+        if ((uint64_t)blocks * ncnt > kNoAllocCounterWords)
+            return fail(c, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: the launch needs more than 2^20 counter words (workgroups x counters per workgroup)");
+        counters = c->static_counters;
+    } else {
+        RT_HIP(c, c->counters.ensure((size_t)blocks * ncnt));
+        counters = c->counters.ptr;
+    }
 
     DevFrame F;
-    F.frame_index = p->frame_index; F.row_begin = rb; F.row_end = re; F.leaf_slots = 0; F.accumulate = p->accumulate; F.seed = p->seed;
+    F.frame_index = p->frame_index; F.row_begin = rb; F.row_end = re; F.tile_row_step = 8u * stride; F.leaf_slots = 0; F.accumulate = p->accumulate; F.seed = p->seed;
     F.rgba = d_rgba8 ? (uint32_t *)d_rgba8 : c->rgba.ptr;
     F.accum = d_accum ? (float *)d_accum : c->accum.ptr;
-    F.counters = c->counters.ptr;
+    F.counters = counters;
     F.diag = nullptr;
 #ifdef RT_DIAG
     static unsigned long long *s_diag = nullptr;
@@ -515,6 +565,7 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
     if (time_kernel) RT_HIP(c, hipEventRecord(c->ev1, s));
     c->kernel_timed = time_kernel;
     c->last_blocks = blocks; c->last_ncnt = ncnt; c->last_events = events; c->timed = true; c->last_stream = s;
+    c->last_counters = counters;
 #ifdef RT_DIAG
     if (getenv("RT_DIAG_PRINT")) {
         std::vector<unsigned long long> all((size_t)n_waves * DG_N);
@@ -528,6 +579,14 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
 #endif
     c->frames += 1;
     return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d_accum, void *stream) {
+    return render_impl(c, p, d_rgba8, d_accum, stream, false);
 }
 
 int32_t rt_resolve_device(rt_ctx *c, uint32_t sample_count, uint32_t row_begin, uint32_t row_end, void *d_accum, void *d_rgba8, void *stream) {
@@ -623,7 +682,7 @@ int32_t rt_get_stats(rt_ctx *c, rt_stats *out) {
         if (c->kernel_timed && hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) out->last_kernel_ms = ms;
         const size_t n = (size_t)c->last_blocks * c->last_ncnt;
         c->h_counters.resize(n);
-        RT_HIP(c, hipMemcpy(c->h_counters.data(), c->counters.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        RT_HIP(c, hipMemcpy(c->h_counters.data(), c->last_counters, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (uint32_t b = 0; b < c->last_blocks; b++) {
             const uint32_t *row = c->h_counters.data() + (size_t)b * c->last_ncnt;
             out->rays_total += row[0];

@@ -37,29 +37,40 @@ def _worker(rank, world, port, mode, out_dir):
         local = torch.from_numpy(r["rgba"])
         full = pkg.gather_row_bands(dist, local, h, rank, world)
         np.save(os.path.join(out_dir, f"rows_{rank}.npy"), full.numpy())
+    elif mode in ("interleaved", "interleaved_ragged"):
+        # the rows mode as bench.py drives it: every world-th 8-row tile row per rank, one all-gather of tile rows
+        if mode == "interleaved_ragged":
+            h = 75   # 10 tile rows, the last one of 3 rows
+        s = pkg.Scene("scene1")
+        cam = s.camera(w, h)
+        xch = pkg.FrameExchange(dist, h, w, rank, world, device="cpu", backend="gloo")
+        rb, re, stride = xch.render_rows()
+        assert (rb, re, stride) == (rank * 8, h, world)
+        frame = xch.frame.numpy()
+        for b, e in pkg.interleaved_tile_rows(h, rank, world):
+            frame[b:e] = orc.render(s.desc, cam, s.textures(), rows=(b, e))["rgba"][b:e]
+        xch.gather_interleaved()
+        np.save(os.path.join(out_dir, f"{mode}_{rank}.npy"), xch.frame[:h].numpy())
     elif mode in ("scatter", "scatter_ragged"):
-        # sample sharding as bench.py drives it: reduce-scatter of accumulators, resolve of the owned rows, all-gather of RGBA8
+        # sample sharding as bench.py drives it: sum of the accumulators, resolve of the owned rows, all-gather of RGBA8
         if mode == "scatter_ragged":
-            h = 75   # not divisible by 2: falls back to all-reduce + 8-row-aligned bands
+            h = 75   # not divisible by 2: 8-row-aligned bands of different sizes
         s = pkg.Scene("scene2")
         cam = s.camera(w, h)
-        acc = np.zeros((h, w, 4), dtype=np.float32)
-        acc_t = torch.from_numpy(acc)
+        xch = pkg.FrameExchange(dist, h, w, rank, world, device="cpu", backend="gloo")
+        assert not xch.reduce_scatter, "reduce-scatter is chosen for RCCL only; gloo sums with an all-reduce"
+        acc = xch.accum.numpy()
         for idx in pkg.shard_samples(6, rank, world):
             orc.render(s.desc, cam, (), frame_index=idx, accumulate=True, seed=0x5EED, accum=acc)
-        rb, re, band = pkg.reduce_scatter_accumulators(dist, acc_t, rank, world)
+        rb, re, band = xch.sum_accumulators()
         assert (re - rb) == band.shape[0] and 0 <= rb < re <= h
         # resolve as render_chunk's accumulation tail does (src/renderer.rs:62-66, :29-36)
         lin = np.clip(band.numpy() / np.float32(6.0), 0.0, 1.0)
         rgba_band = np.stack([(lin[..., 0] * 255.0).astype(np.uint8), (lin[..., 1] * 255.0).astype(np.uint8),
                               (lin[..., 2] * 255.0).astype(np.uint8), np.full(lin.shape[:2], 255, np.uint8)], axis=-1)
-        full = torch.zeros((h, w, 4), dtype=torch.uint8)
-        full[rb:re] = torch.from_numpy(rgba_band)
-        if pkg.equal_row_bands(h, world):
-            pkg.gather_equal_bands(dist, full[rb:re].contiguous(), full)
-        else:
-            full = pkg.gather_row_bands(dist, full, h, rank, world)
-        np.save(os.path.join(out_dir, f"{mode}_{rank}.npy"), full.numpy())
+        xch.frame[rb:re] = torch.from_numpy(rgba_band)
+        xch.gather_bands(rb, re)
+        np.save(os.path.join(out_dir, f"{mode}_{rank}.npy"), xch.frame[:h].numpy())
         np.save(os.path.join(out_dir, f"{mode}_band_{rank}.npy"), np.array([rb, re]))
     else:
         s = pkg.Scene("scene2")
@@ -98,6 +109,26 @@ def test_two_ranks_gloo(pkg, orc, tmp_path, mode):
         # same six samples, summed in a different order: relative 1e-6, far inside the 1e-3 linear budget after /6
         assert np.allclose(a, acc, rtol=1e-6, atol=1e-6)
         assert a[..., 3].min() == 6.0 and a[..., 3].max() == 6.0
+
+
+@pytest.mark.parametrize("mode", ["interleaved", "interleaved_ragged"])
+def test_two_ranks_interleaved_tile_rows(pkg, orc, tmp_path, mode):
+    """The rows mode end to end: interleaved 8-row tile rows, one all-gather, both ranks hold the single-process frame."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, mode, str(tmp_path)), nprocs=2, join=True)
+    w, h = 96, (72 if mode == "interleaved" else 75)
+    s = pkg.Scene("scene1")
+    ref = orc.render(s.desc, s.camera(w, h), s.textures())
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"{mode}_{r}.npy"), ref["rgba"]), f"rank {r} did not reassemble the frame"
+
+
+def test_interleaved_tile_rows_cover_every_row_once(pkg):
+    for h in (1, 8, 9, 72, 75, 2160):
+        for world in (1, 2, 3, 8):
+            rows = sorted(y for r in range(world) for b, e in pkg.interleaved_tile_rows(h, r, world) for y in range(b, e))
+            assert rows == list(range(h))
 
 
 @pytest.mark.parametrize("mode", ["scatter", "scatter_ragged"])

@@ -17,4 +17,6 @@ for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
   name=$(echo "$pass" | cut -d' ' -f1)
   timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$name" -- python3 bench.py --workload "$WL" --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_$name.err" || { echo "pmc pass $name failed"; tail -3 "$OUT/pmc_$name.err"; exit 1; }
 done
+python3 tools/update_hbm_traffic.py collect "$WL" "$OUT" > /dev/null || exit 1
+python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.txt"
 echo done
