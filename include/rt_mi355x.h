@@ -264,6 +264,17 @@ int32_t rt_free_host_frame(rt_ctx *ctx, void *ptr);
  * returns after the launch; the context's other calls wait for it before touching its buffers. */
 int32_t rt_render_device(rt_ctx *ctx, const rt_render_params *params, void *d_rgba8, void *d_accum, void *stream);
 
+/* rt_render_device for callers that cannot allocate device memory while they render (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same frame, same arguments; the
+ * difference is where the launch's per-workgroup counter rows live: in a fixed 4 MiB device array inside the library
+ * instead of a block that rt_render_device grows on demand.  Calls no hipMalloc / hipFree.  Limits: workgroups x counters
+ * per workgroup <= 2^20 (every frame up to 7680x4320 without collect_events; with collect_events about 26 000 workgroups,
+ * e.g. 1280x720), otherwise RT_ERR_UNSUPPORTED.  d_rgba8 / d_accum NULL select the context's own buffers, which
+ * rt_set_camera allocated earlier.  All calls on one GPU share the array (the kernels overwrite every row they own, so
+ * nothing needs clearing between calls): launches that overlap on one GPU -- two contexts, or two streams -- race on it,
+ * and rt_get_stats must be read before the next such launch. */
+int32_t rt_render_device_noalloc(rt_ctx *ctx, const rt_render_params *params, void *d_rgba8, void *d_accum, void *stream);
+
 /* render_chunk's accumulation tail (src/renderer.rs:62-66) on its own: out = to_rgba(clamp(accum / sample_count, 0, 1))
  * for rows [row_begin, row_end) (0,0 = all).  Used when the samples of one frame were rendered by several GPUs and
  * their accumulators summed (all-reduce) outside this library; d_accum/d_rgba8 NULL = the context's own buffers. */

@@ -127,6 +127,7 @@ ABI_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_texture", "rt_set_camera", "rt_render", "rt_render_device",
     "rt_resolve_device", "rt_reset_accum", "rt_read_accum", "rt_get_stats", "rt_context_stream", "rt_device_rgba8", "rt_device_accum", "rt_last_error",
     "rt_abi_version", "rt_alloc_host_frame", "rt_free_host_frame", "rt_update_objects", "rt_read_ray_directions",
+    "rt_render_device_noalloc",
 ]
 
 # RT_MI355X_LIB overrides the library file (used to A/B kernel builds); it is still a HIP build of this backend
@@ -157,6 +158,7 @@ def lib() -> C.CDLL:
         l.rt_set_camera.argtypes = [vp, C.POINTER(rt_camera_desc)]; l.rt_set_camera.restype = C.c_int32
         l.rt_render.argtypes = [vp, C.c_uint32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_size_t]; l.rt_render.restype = C.c_int32
         l.rt_render_device.argtypes = [vp, C.POINTER(rt_render_params), vp, vp, vp]; l.rt_render_device.restype = C.c_int32
+        l.rt_render_device_noalloc.argtypes = [vp, C.POINTER(rt_render_params), vp, vp, vp]; l.rt_render_device_noalloc.restype = C.c_int32
         l.rt_resolve_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]; l.rt_resolve_device.restype = C.c_int32
         l.rt_reset_accum.argtypes = [vp]; l.rt_reset_accum.restype = C.c_int32
         l.rt_read_accum.argtypes = [vp, C.c_void_p, C.c_size_t]; l.rt_read_accum.restype = C.c_int32
@@ -377,7 +379,7 @@ class Context:
         p.tile_row_stride = tile_row_stride
         if stream is None:
             stream = int(self._l.rt_context_stream(self._ctx) or 0)
-        fn = self._l.rt_render_device
+        fn = self._l.rt_render_device_noalloc if noalloc else self._l.rt_render_device
         self._check(fn(self._ctx, C.byref(p), C.c_void_p(d_rgba8 or None), C.c_void_p(d_accum or None), C.c_void_p(stream or None)),
                     "rt_render_device_noalloc" if noalloc else "rt_render_device")
 

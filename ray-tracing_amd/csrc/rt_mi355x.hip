@@ -589,6 +589,10 @@ int32_t rt_render_device(rt_ctx *c, const rt_render_params *p, void *d_rgba8, vo
     return render_impl(c, p, d_rgba8, d_accum, stream, false);
 }
 
+int32_t rt_render_device_noalloc(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d_accum, void *stream) {
+    return render_impl(c, p, d_rgba8, d_accum, stream, true);
+}
+
 int32_t rt_resolve_device(rt_ctx *c, uint32_t sample_count, uint32_t row_begin, uint32_t row_end, void *d_accum, void *d_rgba8, void *stream) {
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!c->has_camera) return fail(c, RT_ERR_STATE, "camera not set");

@@ -1,0 +1,49 @@
+"""rt_render_device_noalloc against rt_render_device, through the C ABI, on a real MI355X.
+
+The no-alloc entry point keeps the launch's per-workgroup counter rows in a fixed device array inside the library
+instead of a block grown with hipMalloc.  It must produce the same frame, accumulator and ray count, bit for bit, on
+two calls in a row, the second with a smaller input (the array then still holds the first call's rows).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(pkg, ctx, torch, name, size, noalloc, events=False):
+    s = pkg.Scene(name)
+    w, h = size
+    ctx.load(s, w, h)
+    rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.render_device(frame_index=1, accumulate=False, seed=0x5EED, collect_events=events, d_rgba8=rgba.data_ptr(),
+                      d_accum=accum.data_ptr(), noalloc=noalloc)
+    st = ctx.stats()   # waits for the launch
+    return rgba.cpu().numpy(), accum.cpu().numpy(), st
+
+
+def test_noalloc_entry_point_equals_render_device_on_two_calls_in_a_row(pkg):
+    import torch
+    ctx = pkg.Context(0)
+    try:
+        # first call: 640x360 with the counting variant (40 counter words per workgroup), then a smaller frame of another
+        # scene through the plain variant, then a ray-marching frame; every one against rt_render_device
+        for name, size, events in (("scene1", (640, 360), True), ("scene3", (200, 120), False), ("scene4", (96, 64), False)):
+            got = _frames(pkg, ctx, torch, name, size, noalloc=True, events=events)
+            want = _frames(pkg, ctx, torch, name, size, noalloc=False, events=events)
+            assert np.array_equal(got[0], want[0]), f"{name} {size}: RGBA8 bytes differ"
+            assert np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32)), f"{name} {size}: accumulator differs"
+            assert got[2]["rays_total"] == want[2]["rays_total"] > 0
+            assert {k: got[2][k] for k in pkg.COUNTER_NAMES} == {k: want[2][k] for k in pkg.COUNTER_NAMES}
+        # beyond the fixed array: 4K with 40 counter words per workgroup
+        s = pkg.Scene("scene3")
+        ctx.load(s, 3840, 2160)
+        with pytest.raises(pkg.BackendError, match="2\\^20 counter words"):
+            ctx.render_device(frame_index=1, collect_events=True, noalloc=True)
+        ctx.render_device(frame_index=1, noalloc=True)          # the plain variant fits at 4K
+        a = ctx.stats()["rays_total"]
+        ctx.render_device(frame_index=1, noalloc=False)
+        assert ctx.stats()["rays_total"] == a
+    finally:
+        ctx.close()
