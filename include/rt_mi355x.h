@@ -214,8 +214,20 @@ typedef struct rt_render_params {
                               * row_begin, row_begin + 8 N, row_begin + 16 N, ... (row_begin a multiple of 8): the
                               * interleaved share of one of N GPUs, the counterpart of the reference's chunk list
                               * dealt round-robin to workers (src/renderer.rs:104-110)                    */
-    uint32_t reserved;
+    uint32_t flags;          /* rt_render_flag bits, 0 for the default behaviour                       */
 } rt_render_params;
+
+/* rt_render_params.flags.  Neither flag changes a pixel. */
+typedef enum rt_render_flag {
+    /* Large diffuse scenes (hierarchy in use, Scene.diffuse set, no refractive material) are normally traced by the
+     * kernel that re-groups rays between bounces; this flag selects the one-lane-per-pixel kernel instead (A/B runs
+     * and tests that compare the two). */
+    RT_RENDER_ONE_LANE_PER_PIXEL = 1,
+    /* With accumulate == 0 the frame's linear value is still written to the accumulator (Renderer.accumulated,
+     * src/renderer.rs:67-68) unless this flag is set: a caller that only displays `img` and never reads the accumulator
+     * back saves 16 of the 20 bytes written per pixel.  Ignored when accumulate != 0. */
+    RT_RENDER_SKIP_ACCUM_STORE = 2
+} rt_render_flag;
 
 /* Creates a context bound to HIP device `device_id` (one context per GPU; one process per GPU
  * in multi-GPU runs).  Replaces nothing in the reference: it owns what Renderer::render keeps on

@@ -30,6 +30,7 @@ REPO_ROOT = os.path.dirname(_HERE)
 RT_SPHERE, RT_TRIANGLE, RT_CUBOID, RT_PLANE, RT_CYLINDER, RT_CONE, RT_UNION, RT_SUBSTRACTION = range(8)
 RT_REFLECTIVE, RT_REFRACTIVE = 0, 1
 RT_DIRECTIONAL, RT_POSITIONAL, RT_SPHERICAL_POSITIONAL = 0, 1, 2
+RT_RENDER_ONE_LANE_PER_PIXEL, RT_RENDER_SKIP_ACCUM_STORE = 1, 2
 
 COUNTER_NAMES = [
     "rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "rays_march", "raygen",
@@ -119,7 +120,7 @@ class rt_stats(C.Structure):
 class rt_render_params(C.Structure):
     _fields_ = [("frame_index", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("accumulate", C.c_int32),
                 ("collect_events", C.c_int32), ("no_timing", C.c_int32), ("seed", C.c_uint64),
-                ("tile_row_stride", C.c_uint32), ("reserved", C.c_uint32)]
+                ("tile_row_stride", C.c_uint32), ("flags", C.c_uint32)]
 
 
 # every symbol include/rt_mi355x.h declares
@@ -363,7 +364,7 @@ class Context:
 
     def render_device(self, frame_index: int = 1, accumulate: bool = False, seed: int = 0x5EED, rows: Optional[tuple] = None,
                       collect_events: bool = False, d_rgba8: int = 0, d_accum: int = 0, stream: Optional[int] = None,
-                      no_timing: bool = False, noalloc: bool = False, tile_row_stride: int = 0):
+                      no_timing: bool = False, noalloc: bool = False, tile_row_stride: int = 0, flags: int = 0):
         """rt_render_device: asynchronous launch into device buffers (0 = the context's own).
 
         `stream` is a hipStream_t handle used as is (0 is HIP's default stream); None selects the context's own stream.
@@ -377,6 +378,7 @@ class Context:
         if rows is not None:
             p.row_begin, p.row_end = rows
         p.tile_row_stride = tile_row_stride
+        p.flags = flags
         if stream is None:
             stream = int(self._l.rt_context_stream(self._ctx) or 0)
         fn = self._l.rt_render_device_noalloc if noalloc else self._l.rt_render_device

@@ -94,6 +94,7 @@ struct RtBvhBuilder {
     std::vector<TreeNode> tree;
     std::vector<uint32_t> *prims;
     std::vector<int> kinds;     // object kind by object index
+    uint32_t max_depth = 0;     // 0: unlimited; else no leaf lies deeper than this many inner nodes below the root (see build)
 
     static float half_area(const RtAabb &b) {
         const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
@@ -101,7 +102,12 @@ struct RtBvhBuilder {
     }
     float centroid2(uint32_t id, int axis) const { return boxes[id].lo[axis] + boxes[id].hi[axis]; }  // twice the centroid
 
-    int32_t build(uint32_t first, uint32_t count) {
+    static uint32_t ceil_log2(uint32_t n) { uint32_t l = 0; while ((1u << l) < n) l++; return l; }
+
+    // `depth`: inner nodes above this one.  With max_depth set, a subtree that could no longer be finished within the limit
+    // by halving is split at the median (a balanced tree over c objects is ceil(log2 c) levels deep), so traversal stacks of
+    // max_depth entries never overflow.
+    int32_t build(uint32_t first, uint32_t count, uint32_t depth = 0) {
         RtAabb box; box.reset();
         float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
         for (uint32_t i = first; i < first + count; i++) {
@@ -122,7 +128,8 @@ struct RtBvhBuilder {
             uint32_t mid = first + count / 2;
             bool split_done = false;
             const float ext = chi[axis] - clo[axis];
-            if (ext > 0.0f && std::isfinite(ext)) {
+            const bool balanced = max_depth != 0u && depth + 1u + ceil_log2(count) >= max_depth;
+            if (!balanced && ext > 0.0f && std::isfinite(ext)) {
                 RtAabb bin_box[kBvhBins]; uint32_t bin_n[kBvhBins];
                 for (int b = 0; b < kBvhBins; b++) { bin_box[b].reset(); bin_n[b] = 0; }
                 const float scale = (float)kBvhBins / ext;
@@ -154,8 +161,8 @@ struct RtBvhBuilder {
                 });
             }
             n.axis = axis;
-            n.left = build(first, mid - first);           // lower centroids along `axis`
-            n.right = build(mid, first + count - mid);
+            n.left = build(first, mid - first, depth + 1u);           // lower centroids along `axis`
+            n.right = build(mid, first + count - mid, depth + 1u);
         }
         tree[(size_t)me] = n;
         return me;
@@ -203,4 +210,112 @@ inline void rt_bvh_build(const rt_scene_desc *d, std::vector<DevBvhNode> &nodes,
         B.emit(0, oct, one);
         nodes.insert(nodes.end(), one.begin(), one.end());
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Second form of the hierarchy, for the kernel that re-groups rays (rt_wavefront.h): only inner nodes, each holding the
+// boxes of BOTH children, so one visit decides about two subtrees and a ray needs half as many dependent fetches.  The
+// boxes are quantised to 16 bits per coordinate on a grid over the root box: a node is 32 bytes (two 16-byte loads)
+// instead of 64, and the whole tree of 10 000 objects is 320 KB.  Traversal uses a small per-lane stack (near child first),
+// so the tree is depth-limited (kBvh2MaxDepth) and needs no per-octant copies.
+// Objects so large that they would stretch the grid (a ground sphere of radius 1000 under spheres of radius 0.5) are left
+// out of this tree and tested linearly, like the planes.
+// ------------------------------------------------------------------------------------------------
+#ifndef RT_WF_STACK
+#define RT_WF_STACK 22
+#endif
+constexpr uint32_t kBvh2MaxDepth = RT_WF_STACK;     // inner levels; the kernel's traversal stack has this many entries
+constexpr uint32_t kBvh2MaxOutliers = 8;
+constexpr uint32_t kBvh2MaxNodes = 1u << 26;   // inner references are byte offsets in 31 bits
+
+struct RtBvh2 {
+    std::vector<DevBvh2Node> nodes;   // inner nodes, depth-first, root first
+    std::vector<uint32_t> linear;     // planes and outliers, ascending object index
+    float origin[3] = {0, 0, 0}, scale[3] = {1, 1, 1};   // decoded coordinate = origin + q * scale
+    bool usable = false;              // at least two objects in the tree
+};
+
+inline void rt_bvh2_build(const rt_scene_desc *d, RtBvh2 &out) {
+    out = RtBvh2();
+    std::vector<uint32_t> prims;
+    RtBvhBuilder B;
+    B.prims = &prims;
+    B.max_depth = kBvh2MaxDepth;
+    B.boxes.resize(d->n_objects);
+    B.kinds.resize(d->n_objects);
+    std::vector<uint32_t> ids;
+    for (uint32_t i = 0; i < d->n_objects; i++) {
+        B.kinds[i] = d->objects[i].kind;
+        if (rt_object_bounds(d->objects[i], B.boxes[i])) ids.push_back(i);
+        else if (d->objects[i].kind == RT_PLANE) out.linear.push_back(i);
+    }
+    // outliers: while taking one object out shrinks the root box's surface at least 16-fold, take it out
+    auto root_of = [&](const std::vector<uint32_t> &v, uint32_t skip) { RtAabb r; r.reset(); for (uint32_t id : v) if (id != skip) r.grow(B.boxes[id]); return r; };
+    for (uint32_t round = 0; round < kBvh2MaxOutliers && ids.size() > 2; round++) {
+        const RtAabb root = root_of(ids, 0xFFFFFFFFu);
+        uint32_t cand[6]; int nc = 0;
+        for (int k = 0; k < 3; k++) {   // the objects that define the root box's six faces
+            uint32_t lo_id = ids[0], hi_id = ids[0];
+            for (uint32_t id : ids) { if (B.boxes[id].lo[k] < B.boxes[lo_id].lo[k]) lo_id = id; if (B.boxes[id].hi[k] > B.boxes[hi_id].hi[k]) hi_id = id; }
+            cand[nc++] = lo_id; cand[nc++] = hi_id;
+        }
+        float best_area = RtBvhBuilder::half_area(root); uint32_t best_id = 0xFFFFFFFFu;
+        for (int c = 0; c < nc; c++) {
+            const float a = RtBvhBuilder::half_area(root_of(ids, cand[c]));
+            if (a < best_area) { best_area = a; best_id = cand[c]; }
+        }
+        if (best_id == 0xFFFFFFFFu || !(best_area * 16.0f <= RtBvhBuilder::half_area(root))) break;
+        ids.erase(std::find(ids.begin(), ids.end(), best_id));
+        out.linear.push_back(best_id);
+    }
+    std::sort(out.linear.begin(), out.linear.end());
+    if (ids.size() < 2) return;
+    B.ids = ids;
+    B.build(0, (uint32_t)B.ids.size());
+    // quantisation grid over the root box: q in [3, 65532] for coordinates inside it, so that the outward rounding below
+    // (floor - 1 / ceil + 1) stays inside 16 bits
+    const RtAabb root = B.tree[0].box;
+    double org[3], scl[3];
+    for (int k = 0; k < 3; k++) {
+        double ext = (double)root.hi[k] - (double)root.lo[k];
+        if (!(ext > 0.0)) ext = 1e-6;
+        scl[k] = (double)(float)(ext / 65529.0 * 1.000001);
+        org[k] = (double)(float)((double)root.lo[k] - 3.0 * scl[k]);
+        out.scale[k] = (float)scl[k]; out.origin[k] = (float)org[k];
+    }
+    auto quant = [&](const RtAabb &b, uint16_t q[6]) {
+        for (int k = 0; k < 3; k++) {
+            double lo = std::floor(((double)b.lo[k] - org[k]) / scl[k]) - 1.0, hi = std::ceil(((double)b.hi[k] - org[k]) / scl[k]) + 1.0;
+            lo = std::min(std::max(lo, 0.0), 65535.0); hi = std::min(std::max(hi, 0.0), 65535.0);
+            q[2 * k] = (uint16_t)lo; q[2 * k + 1] = (uint16_t)hi;   // one dword per axis: lower | upper << 16
+        }
+    };
+    // inner nodes in depth-first order
+    std::vector<int32_t> index_of(B.tree.size(), -1);
+    std::vector<int32_t> order;
+    {
+        std::vector<int32_t> stack{0};
+        while (!stack.empty()) {
+            const int32_t t = stack.back(); stack.pop_back();
+            if (B.tree[(size_t)t].left < 0) continue;
+            index_of[(size_t)t] = (int32_t)order.size(); order.push_back(t);
+            stack.push_back(B.tree[(size_t)t].right); stack.push_back(B.tree[(size_t)t].left);
+        }
+    }
+    auto ref_of = [&](int32_t t) -> int32_t {
+        const RtBvhBuilder::TreeNode &n = B.tree[(size_t)t];
+        if (n.left >= 0) return index_of[(size_t)t] * (int32_t)sizeof(DevBvh2Node);   // inner node: byte offset of the node
+        const uint32_t obj = prims[n.first];
+        return (int32_t)~(((uint32_t)B.kinds[obj] << 28) | obj);   // leaf: one object, named in the reference itself
+    };
+    out.nodes.resize(order.size());
+    for (size_t i = 0; i < order.size(); i++) {
+        const RtBvhBuilder::TreeNode &n = B.tree[(size_t)order[i]];
+        DevBvh2Node g;
+        quant(B.tree[(size_t)n.left].box, g.q);
+        quant(B.tree[(size_t)n.right].box, g.q + 6);
+        g.ref[0] = ref_of(n.left); g.ref[1] = ref_of(n.right);
+        out.nodes[i] = g;
+    }
+    out.usable = !out.nodes.empty() && out.nodes.size() < kBvh2MaxNodes;
 }

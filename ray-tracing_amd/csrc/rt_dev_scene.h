@@ -67,6 +67,14 @@ struct DevBvhNode {
     int32_t leaf;  // -1: inner node (first child = this + 1); else (object kind << 28) | object index
 };
 
+// Two-child node of the quantised hierarchy (rt_bvh.h, rt_bvh2_build): q[0..5] = the first child's box as (lower, upper)
+// pairs for x, y, z (one dword per axis), q[6..11] the second child's, on the 16-bit grid of DevScene.bvh2_origin / bvh2_scale; ref >= 0: byte
+// offset of an inner node in the node array, ref < 0: ~((object kind << 28) | object index).
+struct DevBvh2Node {
+    uint16_t q[12];
+    int32_t ref[2];
+};
+
 struct DevScene {
     const DevObject *objects;
     const DevMaterial *materials;
@@ -76,6 +84,10 @@ struct DevScene {
     const DevBvhNode *bvh_nodes;   // null: linear scan
     const uint32_t *unbounded;     // objects outside the hierarchy (planes), tested linearly
     uint32_t n_bvh_nodes, n_unbounded;
+    const DevBvh2Node *bvh2_nodes; // null: the re-grouping kernel is not used for this scene
+    const uint32_t *bvh2_linear;   // objects outside that tree (planes, outliers), tested linearly
+    uint32_t n_bvh2_linear;
+    float bvh2_origin[3], bvh2_scale[3];
     uint32_t n_objects, n_materials, n_lights, n_sdfs;
     float ambient[3];
     uint32_t max_ray_bounces;

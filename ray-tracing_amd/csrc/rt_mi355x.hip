@@ -19,6 +19,7 @@
 #include "rt_bvh.h"
 #include "rt_dev_scene.h"
 #include "rt_kernels.h"
+#include "rt_wavefront.h"
 
 #pragma clang fp contract(off)
 
@@ -83,6 +84,8 @@ struct rt_ctx {
     DevBuf<DevTexture> textures;
     DevBuf<DevBvhNode> bvh_nodes;
     DevBuf<uint32_t> unbounded;
+    DevBuf<DevBvh2Node> bvh2_nodes;   // quantised two-child hierarchy of the re-grouping path tracer
+    DevBuf<uint32_t> bvh2_linear;
     DevBuf<uint32_t> tex_data[kMaxTextures];
     DevTexture h_textures[kMaxTextures] = {};
     std::vector<int32_t> mat_texture;  // texture index of every material, for the render-time check
@@ -96,6 +99,9 @@ struct rt_ctx {
     DevBuf<uint32_t> rgba;
     DevBuf<float> accum;
     DevBuf<float> ray_dirs;   // Camera.ray_directions: 3 floats per pixel
+    DevBuf<float4> wf_pool;       // ray pools of the re-grouping path tracer: wf_groups x kWfPool entries of 3.5 float4
+    DevBuf<uint32_t> wf_ctrl;     // its tile counter
+    uint32_t wf_groups = 0;       // persistent single-wave workgroups that fit the device (0: not queried yet)
     DevBuf<uint32_t> counters;
     uint32_t *static_counters = nullptr;       // this device's copy of the file-scope `scratch` array (rt_render_device_noalloc)
     const uint32_t *last_counters = nullptr;   // counter table the last render wrote
@@ -223,6 +229,7 @@ void launch(K kernel, dim3 grid, uint32_t threads, size_t lds, hipStream_t s, co
 int32_t upload_hierarchy(rt_ctx *c) {
     DevScene &S = c->scene;
     S.bvh_nodes = nullptr; S.unbounded = nullptr; S.n_bvh_nodes = 0; S.n_unbounded = 0;
+    S.bvh2_nodes = nullptr; S.bvh2_linear = nullptr; S.n_bvh2_linear = 0;
     rt_scene_desc d;
     std::memset(&d, 0, sizeof(d));
     d.objects = c->h_objects.data(); d.n_objects = (uint32_t)c->h_objects.size();
@@ -235,6 +242,19 @@ int32_t upload_hierarchy(rt_ctx *c) {
     if (!unbounded.empty()) RT_HIP(c, hipMemcpy(c->unbounded.ptr, unbounded.data(), unbounded.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     S.bvh_nodes = c->bvh_nodes.ptr; S.unbounded = c->unbounded.ptr;
     S.n_bvh_nodes = (uint32_t)(nodes.size() / kBvhLayouts); S.n_unbounded = (uint32_t)unbounded.size();
+    // the second form of the hierarchy, for the kernel that re-groups rays: only scenes that kernel can render
+    if (S.diffuse && !c->has_refractive) {
+        RtBvh2 b2;
+        rt_bvh2_build(&d, b2);
+        if (b2.usable) {
+            RT_HIP(c, c->bvh2_nodes.ensure(b2.nodes.size()));
+            RT_HIP(c, c->bvh2_linear.ensure(b2.linear.size() ? b2.linear.size() : 1));
+            RT_HIP(c, hipMemcpy(c->bvh2_nodes.ptr, b2.nodes.data(), b2.nodes.size() * sizeof(DevBvh2Node), hipMemcpyHostToDevice));
+            if (!b2.linear.empty()) RT_HIP(c, hipMemcpy(c->bvh2_linear.ptr, b2.linear.data(), b2.linear.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            S.bvh2_nodes = c->bvh2_nodes.ptr; S.bvh2_linear = c->bvh2_linear.ptr; S.n_bvh2_linear = (uint32_t)b2.linear.size();
+            for (int k = 0; k < 3; k++) { S.bvh2_origin[k] = b2.origin[k]; S.bvh2_scale[k] = b2.scale[k]; }
+        }
+    }
     return RT_OK;
 }
 
@@ -274,9 +294,9 @@ void rt_destroy(rt_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (const auto &r : c->pinned) (void)hipHostFree(r.first);
     c->objects.release(); c->materials.release(); c->lights.release(); c->sdfs.release(); c->textures.release();
-    c->bvh_nodes.release(); c->unbounded.release();
+    c->bvh_nodes.release(); c->unbounded.release(); c->bvh2_nodes.release(); c->bvh2_linear.release();
     for (auto &t : c->tex_data) t.release();
-    c->rgba.release(); c->accum.release(); c->ray_dirs.release(); c->counters.release();
+    c->rgba.release(); c->accum.release(); c->ray_dirs.release(); c->counters.release(); c->wf_pool.release(); c->wf_ctrl.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->evc0) (void)hipEventDestroy(c->evc0);
@@ -499,10 +519,32 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
     // tile rows of this launch: every stride-th 8-row band of [rb, re)
     const uint32_t tiles_x = (c->camera.width + 7u) / 8u, tiles_y = ((re - rb + 7u) / 8u + stride - 1u) / stride;
     // 2-D grid: y = tile row, x = group of waves_per_block tile columns
-    const dim3 grid((tiles_x + waves_per_block - 1u) / waves_per_block, tiles_y);
-    const uint32_t blocks = grid.x * grid.y;
+    dim3 grid((tiles_x + waves_per_block - 1u) / waves_per_block, tiles_y);
+    uint32_t blocks = grid.x * grid.y;
     const uint64_t n_waves = (uint64_t)blocks * waves_per_block;  // diagnostic builds size their table by it
     (void)n_waves;
+    // Large diffuse scenes without refractive materials: persistent wavefronts that re-group their rays between bounces
+    // (rt_wavefront.h).  The counting variant, the no-alloc entry point and the A/B flag keep the one-lane-per-pixel kernel.
+    const bool regroup = !S.ray_marching && S.bvh2_nodes && S.diffuse && !c->has_refractive && maxd >= 1u && !events && !noalloc &&
+                         !(p->flags & RT_RENDER_ONE_LANE_PER_PIXEL);
+    WfArgs W = {};
+    if (regroup) {
+        if (c->wf_groups == 0u) {
+            int per_cu = 0, cus = 0;
+            RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_wf_diffuse_kernel, 64, 0));
+            RT_HIP(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            if (per_cu <= 0 || cus <= 0) return fail(c, RT_ERR_DEVICE, "occupancy query of the path tracing kernel failed");
+            c->wf_groups = (uint32_t)per_cu * (uint32_t)cus;
+        }
+        W.tiles_x = (c->camera.width + kWfTileW - 1u) / kWfTileW; W.tiles_y = tiles_y;
+        grid = dim3(std::min<uint32_t>(c->wf_groups, W.tiles_x * W.tiles_y));
+        blocks = grid.x;
+        RT_HIP(c, c->wf_pool.ensure((size_t)c->wf_groups * kWfPool * 4u));   // four float4 planes per pool entry
+        RT_HIP(c, c->wf_ctrl.ensure(16));
+        const size_t plane = (size_t)c->wf_groups * kWfPool;
+        W.a = c->wf_pool.ptr; W.b = W.a + plane; W.c = W.b + plane; W.d = W.c + plane;
+        W.tile_counter = c->wf_ctrl.ptr;
+    }
     const uint32_t ncnt = (events ? (uint32_t)RT_CNT_COUNT : 0u) + 1u;
     uint32_t *counters = nullptr;
     if (noalloc) {
@@ -532,7 +574,25 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
     // the two timing events cost about 6 us per launch on the stream; callers that time their own stream opt out
     const bool time_kernel = p->no_timing == 0;
     if (time_kernel) RT_HIP(c, hipEventRecord(c->ev0, s));
-    if (S.ray_marching) {
+    if (regroup) {
+        RT_HIP(c, hipMemsetAsync(W.tile_counter, 0, sizeof(uint32_t), s));
+#ifdef RT_WF_STATS
+        static unsigned long long *s_wfstats = nullptr;
+        if (!s_wfstats) (void)hipMalloc((void **)&s_wfstats, 2 * WS_N * sizeof(unsigned long long));
+        (void)hipMemsetAsync(s_wfstats, 0, 2 * WS_N * sizeof(unsigned long long), s);
+        W.stats = s_wfstats;
+#endif
+        hipLaunchKernelGGL(rt_wf_diffuse_kernel, grid, dim3(64), 0, s, S, c->camera, F, W);
+#ifdef RT_WF_STATS
+        if (getenv("RT_WF_STATS_PRINT")) {
+            unsigned long long h[2 * WS_N];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h, s_wfstats, sizeof(h), hipMemcpyDeviceToHost);
+            static const char *names[WS_N] = {"refill", "walk step", "leaf test", "finish", "shade batch", "prepare batch"};
+            for (int i = 0; i < WS_N; i++) fprintf(stderr, "WFSTAT %-14s runs %12llu lanes %14llu  mean lanes %5.1f\n", names[i], h[2 * i], h[2 * i + 1], h[2 * i] ? (double)h[2 * i + 1] / (double)h[2 * i] : 0.0);
+        }
+#endif
+    } else if (S.ray_marching) {
         // up to 16 leaves (48 KiB of LDS per workgroup) keep their object-space rays in LDS during the march loop
         const bool cache = c->leaf_slots >= 1u && c->leaf_slots <= (uint32_t)RT_MARCH_CACHE_MAX_SLOTS;
         F.leaf_slots = cache ? c->leaf_slots : 0u;

@@ -1,0 +1,332 @@
+// rt_wavefront.h — path tracing of large diffuse scenes with re-grouped rays.
+//
+// What it computes: Scene::pixel for scenes with `diffuse` set and no refractive material, i.e. RayTracing::color_diffuse's
+// reflective arm (src/ray_tracing/ray_tracing.rs:80-114, :155-157) over RayTracing::trace_ray (:59-78), then render_chunk's
+// accumulate / clamp / to_rgba (src/renderer.rs:59-75).  color_diffuse returns its child's value unchanged, so a path is a
+// forward loop: trace, on a miss return light + ambient * contribution, on a hit add the emission, draw the next direction.
+//
+// Why a second formulation next to rt_trace_kernel: with one pixel per lane for a whole path, the lanes of a wavefront
+// disagree on how many bounces their path has and on how many hierarchy nodes each ray visits; on the 10 000-sphere
+// workload 30 % of the lanes did useful work.  Here a wavefront owns a pool of kWfPool paths (a 64x8 pixel tile) and
+// works on it bounce by bounce:
+//   trace   lanes pull rays from the pool as they finish the previous one (refilled in batches, when enough lanes are
+//           idle), so a short traversal does not wait for the longest one of its wavefront.  A lane whose ray reaches a
+//           leaf parks until enough lanes have a leaf to test, so the candidate test runs with many lanes instead of a few.
+//   shade   64 hits at a time, all lanes in the same code; the paths that go on are written back to the pool compacted
+//           (ballot + prefix count), so the next bounce starts with full wavefronts whatever the paths' lengths.
+// The pool (ray, carried light, contribution, RNG key, pixel) lives in a per-wavefront slice of a device buffer that is
+// rewritten every bounce and stays cache resident; the (distance, object) results of a trace pass live in LDS.
+// Every path does the arithmetic it does in rt_trace_kernel, in the same order: frames are bit-identical.
+#pragma once
+#include "rt_kernels.h"
+
+#pragma clang fp contract(off)
+
+#ifndef RT_WF_POOL
+#define RT_WF_POOL 512
+#endif
+#ifndef RT_WF_WALK_EIGHTHS
+#define RT_WF_WALK_EIGHTHS 5   // the walk loop goes on while this many eighths of the lanes that hold a ray are walking
+#endif
+constexpr uint32_t kWfPool = RT_WF_POOL;              // paths per wavefront pool = pixels per tile
+constexpr uint32_t kWfTileW = kWfPool / 8u, kWfTileH = 8u;   // tile = sub-tiles of 8x8 pixels side by side
+#ifndef RT_WF_STACK
+#define RT_WF_STACK 22
+#endif
+constexpr uint32_t kWfStack = RT_WF_STACK;            // traversal stack entries per lane (>= kBvh2MaxDepth of rt_bvh.h)
+constexpr uint32_t kWfHitMiss = 0xFFFFFFFFu, kWfHitInvalid = 0xFFFFFFFEu;
+
+#ifndef RT_WF_REFILL
+#define RT_WF_REFILL 16      // idle lanes that trigger a refill from the pool
+#endif
+#ifndef RT_WF_WAVES
+#define RT_WF_WAVES 7        // wavefronts per SIMD the kernel is compiled for
+#endif
+
+// Diagnostic build (-DRT_WF_STATS): per phase, how often it ran and with how many lanes (never enabled in the shipped library).
+enum { WS_REFILL = 0, WS_WALK, WS_LEAF, WS_FINISH, WS_SHADE, WS_PREPARE, WS_N };
+#ifdef RT_WF_STATS
+#define WS_ADD(ph, mask) do { const uint64_t m_ = (mask); if (threadIdx.x == 0u) { s_stat[2 * (ph)] += 1u; s_stat[2 * (ph) + 1] += (uint32_t)__popcll(m_); } } while (0)
+#define WS_PARAM , uint32_t *s_stat
+#define WS_PASS , s_stat
+#else
+#define WS_ADD(ph, mask) do { } while (0)
+#define WS_PARAM
+#define WS_PASS
+#endif
+
+struct WfArgs {
+    float4 *a;   // per pool entry: ray origin xyz, RNG key
+    float4 *b;   //                 ray direction xyz, pixel index
+    float4 *c;   //                 carried light xyz, contribution x
+    float4 *d;   //                 contribution y, z; closest hit so far: distance, object | sub << 30 (kWfHitMiss: none)
+    uint32_t *tile_counter;   // next tile to hand out (zeroed before the launch)
+    uint32_t tiles_x, tiles_y;
+    unsigned long long *stats;   // diagnostic builds only
+};
+
+// pixel of pool slot j in stage 0: sub-tile j / 64, lane-in-tile j % 64 as in lane_pixel
+RT_DEV bool wf_slot_pixel(const DevCamera &C, const DevFrame &F, uint32_t x0, uint32_t y0, uint32_t j, uint32_t &pos) {
+    const uint32_t l = j & 63u;
+    const uint32_t x = x0 + (j >> 6) * 8u + (l & 7u), y = y0 + (l >> 3);
+    pos = y * C.width + x;
+    return x < C.width && y < F.row_end;
+}
+
+RT_DEV float rt_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+RT_DEV float rt_min3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+
+RT_DEV uint32_t wf_pack_hit(int best, int best_sub) { return best < 0 ? kWfHitMiss : ((uint32_t)best | ((uint32_t)best_sub << 30)); }
+
+// trace_ray's scan over the objects outside the hierarchy (planes, outliers): wave-uniform loop, scalar loads, the
+// reference's acceptance rule.  Runs with all lanes busy (shade phase), not inside the traversal.
+RT_DEV void wf_linear_objects(const DevScene &S, f3 ro, f3 rd, float &closest, int &best, int &best_sub) {
+    Cnt<false> nocnt;
+    for (uint32_t k = 0; k < S.n_bvh2_linear; k++) {
+        const uint32_t idx = S.bvh2_linear[k];
+        const DevObject &o = S.objects[idx];
+        float t = 0.0f;
+        int sub = 0;
+        if (cand_any<false>(o.kind, o, ro, rd, t, sub, nocnt) && t > 0.0f && (t < closest || (t == closest && (int)idx < best))) { closest = t; best = (int)idx; best_sub = sub; }
+    }
+}
+
+// trace_ray for the n rays of the pool (stage 0: the tile's camera rays).  In: pd[j].zw = closest hit among the linear
+// objects; out: pd[j].zw = closest hit overall (t bits, object | sub << 30).
+RT_DEV void wf_trace_pool(const DevScene &S, const DevCamera &C, const DevFrame &F, bool primary, uint32_t n, uint32_t x0, uint32_t y0,
+                          const float4 *pa, const float4 *pb, float4 *pd, uint32_t *s_stack, uint32_t &rays WS_PARAM) {
+    const char *nodes = reinterpret_cast<const char *>(S.bvh2_nodes);   // inner references are byte offsets into this array
+    const f3 gorg = ld3(S.bvh2_origin), gscl = ld3(S.bvh2_scale);
+    uint32_t *stack = s_stack + threadIdx.x;   // entry e of this lane at stack[e * 64]
+    uint32_t next = 0u;   // wave-uniform: first pool slot not handed out yet
+    int ridx = -1;        // pool slot this lane is tracing, -1: idle
+    int cur = -1;         // inner node to visit next, -1: none left
+    int pend0 = 0, pend1 = 0;   // leaves waiting for their candidate test (negative references), 0: none
+    uint32_t sp = 0u;
+    f3 ro = splat3(0.0f), rd = splat3(0.0f), ka = splat3(0.0f), kb = splat3(0.0f);
+    struct { uint32_t x, y, z; } rot = {0u, 0u, 0u};   // 16 where the direction component is negative
+    int best = -1, best_sub = 0;
+    float closest = RT_F32_MAX;
+    Cnt<false> nocnt;
+    for (;;) {
+        const uint64_t busy = __ballot(ridx >= 0);
+        if (next < n && (64 - __popcll(busy) >= RT_WF_REFILL || busy == 0ull)) {
+            // ---- refill: idle lanes take the next pool slots in lane order
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(~busy >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)~busy, 0u));
+            WS_ADD(WS_REFILL, ~busy);
+            if (ridx < 0) {
+                const uint32_t j = next + rank;
+                if (j < n) {
+                    bool valid = true;
+                    if (primary) {
+                        uint32_t pos;
+                        valid = wf_slot_pixel(C, F, x0, y0, j, pos);
+                        if (valid) { ro = ld3(C.position); rd = ld3(C.ray_dirs + 3u * (size_t)pos); }
+                    } else {
+                        const float4 A = pa[j], B = pb[j];
+                        ro = mk3(A.x, A.y, A.z); rd = mk3(B.x, B.y, B.z);
+                    }
+                    if (valid) {
+                        const float2 h0 = *reinterpret_cast<const float2 *>(&pd[j].z);
+                        ridx = (int)j;
+                        rays += 1u;
+                        closest = h0.x;
+                        const uint32_t hb = __float_as_uint(h0.y);
+                        best = hb == kWfHitMiss ? -1 : (int)(hb & 0x0FFFFFFFu); best_sub = hb == kWfHitMiss ? 0 : (int)(hb >> 30);
+                        pend0 = 0; pend1 = 0; sp = 0u; cur = 0;
+                        // box test on the 16-bit grid: t = (origin + q * scale - ro) / rd = q * ka + kb
+                        // (the box test only steers the traversal: an approximate reciprocal is as good as the exact quotient)
+                        const f3 inv = mk3(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));
+                        ka = gscl * inv;
+                        kb = (gorg - ro) * inv;
+                        rot.x = (__float_as_uint(rd.x) >> 31) << 4; rot.y = (__float_as_uint(rd.y) >> 31) << 4; rot.z = (__float_as_uint(rd.z) >> 31) << 4;
+                    }
+                }
+            }
+            const uint32_t take = 64u - (uint32_t)__popcll(busy);
+            next = (n - next < take) ? n : next + take;
+        }
+        const uint64_t active = __ballot(ridx >= 0);
+        if (active == 0ull) {
+            if (next >= n) break;
+            continue;   // only slots outside the frame were handed out: refill again
+        }
+        // ---- walk: lanes visit inner nodes until a child that is a leaf is hit (they park) or no node is left; the
+        //      loop goes on while at least three quarters of the lanes that hold a ray are still walking
+        const int walk_min = (__popcll(active) * RT_WF_WALK_EIGHTHS) >> 3;
+        bool w = ridx >= 0 && cur >= 0 && pend0 == 0;
+        const int walk_floor = walk_min > 1 ? walk_min : 1;
+        const bool walked = __popcll(__ballot(w)) >= walk_floor;
+        if (walked) do {
+            WS_ADD(WS_WALK, __ballot(w));
+            if (w) {
+                const uint4 n0 = *reinterpret_cast<const uint4 *>(nodes + (uint32_t)cur);
+                const uint4 n1 = *reinterpret_cast<const uint4 *>(nodes + (uint32_t)cur + 16u);
+                // per axis one dword = lower | upper << 16; rotating it by 0 or 16 bits (the sign of the direction) puts the
+                // plane the ray meets first into the low half, so no per-axis min / max is needed
+                const uint32_t lx = __builtin_amdgcn_alignbit(n0.x, n0.x, rot.x), ly = __builtin_amdgcn_alignbit(n0.y, n0.y, rot.y), lz = __builtin_amdgcn_alignbit(n0.z, n0.z, rot.z);
+                const uint32_t rx = __builtin_amdgcn_alignbit(n0.w, n0.w, rot.x), ry = __builtin_amdgcn_alignbit(n1.x, n1.x, rot.y), rz = __builtin_amdgcn_alignbit(n1.y, n1.y, rot.z);
+                // a NaN (0 * inf, inf - inf for rays parallel to an axis) is dropped by max3 / min3: such a slab does not cull
+                const float ltmin = rt_max3(__builtin_fmaf((float)(lx & 0xFFFFu), ka.x, kb.x), __builtin_fmaf((float)(ly & 0xFFFFu), ka.y, kb.y), rt_max(__builtin_fmaf((float)(lz & 0xFFFFu), ka.z, kb.z), 0.0f));
+                const float ltmax = rt_min3(__builtin_fmaf((float)(lx >> 16), ka.x, kb.x), __builtin_fmaf((float)(ly >> 16), ka.y, kb.y), __builtin_fmaf((float)(lz >> 16), ka.z, kb.z));
+                const float rtmin = rt_max3(__builtin_fmaf((float)(rx & 0xFFFFu), ka.x, kb.x), __builtin_fmaf((float)(ry & 0xFFFFu), ka.y, kb.y), rt_max(__builtin_fmaf((float)(rz & 0xFFFFu), ka.z, kb.z), 0.0f));
+                const float rtmax = rt_min3(__builtin_fmaf((float)(rx >> 16), ka.x, kb.x), __builtin_fmaf((float)(ry >> 16), ka.y, kb.y), __builtin_fmaf((float)(rz >> 16), ka.z, kb.z));
+                const bool lhit = ltmin <= ltmax && ltmin <= closest, rhit = rtmin <= rtmax && rtmin <= closest;
+                const int lref = (int)n1.z, rref = (int)n1.w;
+                // leaves whose box is hit wait for their candidate test; inner children are visited near one first
+                const bool lleaf = lhit && lref < 0, rleaf = rhit && rref < 0;
+                pend0 = lleaf ? lref : (rleaf ? rref : 0);
+                pend1 = (lleaf && rleaf) ? rref : 0;
+                const bool lin = lhit && lref >= 0, rin = rhit && rref >= 0;
+                const bool rfirst = rin && (!lin || rtmin < ltmin);   // the second child is the one to visit next
+                cur = rfirst ? rref : (lin ? lref : -1);
+                if (lin && rin) {            // both: the farther one waits on the stack (sp counts bytes of this lane's column)
+                    *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(stack) + sp) = (uint32_t)(rfirst ? lref : rref);
+                    sp += 256u;
+                }
+                if (!lin && !rin && sp > 0u) {   // neither: back to the last one that waits
+                    sp -= 256u;
+                    cur = (int)*reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(stack) + sp);
+                }
+                w = cur >= 0 && pend0 == 0;
+            }
+        } while (__popcll(__ballot(w)) >= walk_floor);
+        // ---- candidate tests of the parked leaves' objects (the reference's intersect() up to `distance`)
+        // (one test per lane and round: a lane with a second leaf stays parked and joins the next round, which then has
+        // more lanes, instead of running a round of its own)
+        if (__ballot(pend0 != 0) != 0ull) {
+            WS_ADD(WS_LEAF, __ballot(pend0 != 0));
+            if (pend0 != 0) {
+                const uint32_t leaf = ~(uint32_t)pend0;
+                const int idx = (int)(leaf & 0x0FFFFFFFu);
+                float t = 0.0f;
+                int sub = 0;
+                if (cand_any<false>((int)(leaf >> 28), S.objects[idx], ro, rd, t, sub, nocnt) && t > 0.0f && (t < closest || (t == closest && idx < best))) {
+                    closest = t; best = idx; best_sub = sub;
+                }
+                pend0 = pend1; pend1 = 0;
+            }
+        }
+        // ---- rays with no node left are done
+        WS_ADD(WS_FINISH, __ballot(ridx >= 0 && cur < 0 && pend0 == 0));
+        if (ridx >= 0 && cur < 0 && pend0 == 0) {
+            *reinterpret_cast<float2 *>(&pd[ridx].z) = make_float2(closest, __uint_as_float(wf_pack_hit(best, best_sub)));
+            ridx = -1;
+        }
+    }
+}
+
+// One persistent wavefront per workgroup; tiles are handed out through an atomic counter, bottom rows first.
+__global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_diffuse_kernel(const DevScene S, const DevCamera C, const DevFrame F, const WfArgs W) {
+    __shared__ uint32_t s_stack[kWfStack * 64u];
+    const uint32_t lane = threadIdx.x;
+    float4 *pa = W.a + (size_t)blockIdx.x * kWfPool, *pb = W.b + (size_t)blockIdx.x * kWfPool, *pc = W.c + (size_t)blockIdx.x * kWfPool;
+    float4 *pd = W.d + (size_t)blockIdx.x * kWfPool;
+    const uint32_t maxd = S.max_ray_bounces;
+    const uint32_t n_tiles = W.tiles_x * W.tiles_y;
+    const f3 ambient = ld3(S.ambient);
+    const bool jitter = S.enable_accumulation != 0u;
+    uint32_t rays = 0u;
+    Cnt<false> nocnt;
+#ifdef RT_WF_STATS
+    __shared__ uint32_t s_stat[2 * WS_N];
+    if (lane < 2u * WS_N) s_stat[lane] = 0u;
+    __syncthreads();
+#endif
+    for (;;) {
+        uint32_t tile = 0u;
+        if (lane == 0u) tile = atomicAdd(W.tile_counter, 1u);
+        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+        if (tile >= n_tiles) break;
+        const uint32_t trow = tile / W.tiles_x, tx = tile - trow * W.tiles_x;
+        const uint32_t x0 = tx * kWfTileW, y0 = F.row_begin + (W.tiles_y - 1u - trow) * F.tile_row_step;
+        // ---- camera rays against the linear objects, all lanes busy
+        for (uint32_t base = 0u; base < kWfPool; base += 64u) {
+            const uint32_t j = base + lane;
+            uint32_t pos;
+            float closest = RT_F32_MAX;
+            int best = -1, best_sub = 0;
+            WS_ADD(WS_PREPARE, ~0ull);
+            if (wf_slot_pixel(C, F, x0, y0, j, pos)) wf_linear_objects(S, ld3(C.position), ld3(C.ray_dirs + 3u * (size_t)pos), closest, best, best_sub);
+            else best = (int)kWfHitInvalid;   // slot outside the frame: never traced, never shaded
+            pd[j] = make_float4(1.0f, 1.0f, closest, __uint_as_float(best == (int)kWfHitInvalid ? kWfHitInvalid : wf_pack_hit(best, best_sub)));
+        }
+        __syncthreads();
+        uint32_t n = kWfPool;
+        for (uint32_t depth = 0u; depth < maxd && n > 0u; depth++) {
+            const bool primary = depth == 0u;
+            wf_trace_pool(S, C, F, primary, n, x0, y0, pa, pb, pd, s_stack, rays WS_PASS);
+            __syncthreads();
+            // ---- shade: color_diffuse at every hit / miss of this bounce (ray_tracing.rs:87-114, :155-157)
+            uint32_t out = 0u;
+            for (uint32_t base = 0u; base < n; base += 64u) {
+                const uint32_t j = base + lane;
+                bool alive = j < n;
+                float4 D = make_float4(1.0f, 1.0f, 0.0f, __uint_as_float(kWfHitInvalid));
+                if (alive) D = pd[j];
+                const uint32_t hobj = __float_as_uint(D.w);
+                alive = alive && hobj != kWfHitInvalid;
+                WS_ADD(WS_SHADE, __ballot(alive));
+                f3 ro = splat3(0.0f), rd = splat3(0.0f), L = splat3(0.0f), Cc = splat3(1.0f);
+                uint32_t key = 0u, pos = 0u;
+                if (alive) {
+                    if (primary) {
+                        (void)wf_slot_pixel(C, F, x0, y0, j, pos);
+                        ro = ld3(C.position); rd = ld3(C.ray_dirs + 3u * (size_t)pos);
+                        key = rt_rng_path_key(F.seed, pos, F.frame_index);
+                    } else {
+                        const float4 A = pa[j], B = pb[j], Cv = pc[j];
+                        ro = mk3(A.x, A.y, A.z); key = __float_as_uint(A.w);
+                        rd = mk3(B.x, B.y, B.z); pos = __float_as_uint(B.w);
+                        L = mk3(Cv.x, Cv.y, Cv.z); Cc = mk3(Cv.w, D.x, D.y);
+                    }
+                }
+                bool goes_on = false;
+                f3 no = splat3(0.0f), nd = splat3(0.0f), p = splat3(0.0f), cc = splat3(0.0f);
+                float nclosest = RT_F32_MAX;
+                int nbest = -1, nbest_sub = 0;
+                if (alive) {
+                    if (hobj == kWfHitMiss) {
+                        store_pixel(F, pos, L + ambient * Cc);
+                    } else {
+                        const int obj = (int)(hobj & 0x0FFFFFFFu), sub = (int)(hobj >> 30);
+                        HitRec h; Mtl m;
+                        h.u = 0.0f; h.v = 0.0f;
+                        const DevObject &o = S.objects[obj];
+                        finalize_one<false>(o, S.materials[o.material], ro, rd, D.z, sub, h, m, nocnt);
+                        f3 albedo = m.albedo;
+                        if (m.texture >= 0) albedo = tex_from_uv(S.textures[m.texture], h.u, h.v);
+                        p = L + m.emission_power * albedo;
+                        rt_reflection_ray(rd, h, m.roughness, key, true, jitter, no, nd);
+                        cc = Cc * albedo;
+                        if (depth + 1u >= maxd) store_pixel(F, pos, p);   // the child at the depth limit returns its light_color (:83-85)
+                        else goes_on = true;
+                    }
+                }
+                // the next ray against the linear objects (wave-uniform loop: kept outside the divergent code above)
+                if (S.n_bvh2_linear != 0u && __ballot(goes_on) != 0ull) {
+                    if (goes_on) wf_linear_objects(S, no, nd, nclosest, nbest, nbest_sub);
+                }
+                // every lane has read its slot: the compacted writes below never reach a slot that is still unread
+                const uint64_t on = __ballot(goes_on);
+                if (goes_on) {
+                    const uint32_t k = out + __builtin_amdgcn_mbcnt_hi((uint32_t)(on >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)on, 0u));
+                    pa[k] = make_float4(no.x, no.y, no.z, __uint_as_float(rt_rng_child_key(key, 0u)));
+                    pb[k] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(pos));
+                    pc[k] = make_float4(p.x, p.y, p.z, cc.x);
+                    pd[k] = make_float4(cc.y, cc.z, nclosest, __uint_as_float(wf_pack_hit(nbest, nbest_sub)));
+                }
+                out += (uint32_t)__popcll(on);
+            }
+            __syncthreads();   // pool writes of all lanes before the next bounce reads them
+            n = out;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_xor(rays, off, 64);
+    if (lane == 0u) F.counters[blockIdx.x] = rays;
+#ifdef RT_WF_STATS
+    __syncthreads();
+    if (lane < 2u * WS_N && W.stats) atomicAdd(&W.stats[lane], (unsigned long long)s_stat[lane]);
+#endif
+}

@@ -504,6 +504,36 @@ def test_hierarchy_traversal_equals_linear_scan_on_sphere_fields(pkg, orc, ctx, 
     assert 0 < st["test_sphere"] < cref["test_sphere"] / 4 and st["bvh_node"] > 0, "the hierarchy must cull most candidates"
 
 
+@pytest.mark.parametrize("size", [(7, 5), (64, 8), (65, 9), (200, 150), (1000, 300)])
+@pytest.mark.parametrize("name,bounces", [("spheres1k", 5), ("spheres200", 1), ("spheres200", 9)])
+def test_regrouping_path_tracer_equals_the_one_lane_per_pixel_kernel(pkg, ctx, name, bounces, size):
+    """Large diffuse scenes run on persistent wavefronts that re-group their rays between bounces; the flag
+    RT_RENDER_ONE_LANE_PER_PIXEL selects the plain kernel.  Same paths, same arithmetic: accumulator, bytes and ray count
+    are identical, for whole frames, row ranges and interleaved shares, over three accumulated samples."""
+    import torch
+    s = pkg.Scene(name)
+    s.desc.max_ray_bounces = bounces
+    w, h = size
+    ctx.load(s, w, h)
+    bufs = {}
+    for flags in (0, pkg.RT_RENDER_ONE_LANE_PER_PIXEL):
+        rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        rays = []
+        for f in (1, 2, 3):
+            ctx.render_device(frame_index=f, accumulate=True, seed=21, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), flags=flags)
+            rays.append(ctx.stats()["rays_total"])
+        if h >= 24:
+            ctx.render_device(frame_index=4, accumulate=True, seed=21, rows=(8, h - 3), d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), flags=flags)
+            rays.append(ctx.stats()["rays_total"])
+            ctx.render_device(frame_index=5, accumulate=True, seed=21, rows=(8, h), tile_row_stride=3, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), flags=flags)
+            rays.append(ctx.stats()["rays_total"])
+        bufs[flags] = (rgba.cpu().numpy(), accum.cpu().numpy(), rays)
+    a, b = bufs[0], bufs[pkg.RT_RENDER_ONE_LANE_PER_PIXEL]
+    assert a[2] == b[2] and a[2][0] >= w * h
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[0], b[0])
+
+
 def test_ten_thousand_sphere_scene_at_reduced_size(pkg, orc, ctx):
     """The 8K multi-sample workload's scene (10 000 spheres, diffuse, emissive every 16th) at a size the linear-scan
     oracle finishes in seconds: two accumulated samples, bit for bit."""
@@ -540,6 +570,12 @@ def test_ten_thousand_sphere_scene_at_full_size_properties(pkg, orc, ctx):
     b = ctx.read_accum()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "row bands or a repeated seed changed the frame"
     assert band_rays == rays
+    # the one-lane-per-pixel kernel traces the same paths as the re-grouping one
+    ctx.reset_accum()
+    ctx.render_device(frame_index=1, accumulate=True, seed=0x5EED, flags=pkg.RT_RENDER_ONE_LANE_PER_PIXEL)
+    b = ctx.read_accum()
+    assert ctx.stats()["rays_total"] == rays
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "the two kernels disagree on the 8K frame"
     # coarse statistics: means over a 6x8 grid of blocks of one 8K sample against 16 oracle samples of a 128x72 frame
     # (tolerances calibrated oracle-against-oracle: emissive spheres make the per-block means heavy-tailed)
     big = a[..., :3].reshape(6, 720, 8, 960, 3).mean(axis=(1, 3))

@@ -23,7 +23,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RENDER_KERNELS = ("rt_trace_kernel<false", "rt_march_kernel<false", "rt_wf_")   # timed variants; the counting variants are <true, ...>
-ONCE_PER_CALL = ("rt_trace_kernel<false", "rt_march_kernel<false", "rt_wf_primary_kernel")
+ONCE_PER_CALL = ("rt_trace_kernel<false", "rt_march_kernel<false", "rt_wf_diffuse_kernel")
 
 
 def sha256(path):
