@@ -102,6 +102,8 @@ struct rt_ctx {
     DevBuf<float4> wf_pool;       // ray pools of the re-grouping path tracer: wf_groups x kWfPool entries of 3.5 float4
     DevBuf<uint32_t> wf_ctrl;     // its tile counter
     uint32_t wf_groups = 0;       // persistent single-wave workgroups that fit the device (0: not queried yet)
+    uint64_t wf_order_key = 0;    // frame / row range the tile-row costs in wf_ctrl belong to
+    uint32_t scene_serial = 0;    // bumped by rt_set_scene, rt_update_objects and rt_set_camera
     DevBuf<uint32_t> counters;
     uint32_t *static_counters = nullptr;       // this device's copy of the file-scope `scratch` array (rt_render_device_noalloc)
     const uint32_t *last_counters = nullptr;   // counter table the last render wrote
@@ -391,6 +393,7 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
             c->leaf_slots += march_leaf_slots(d, d->sdfs[k], 2);
         }
     }
+    c->scene_serial += 1u;
     c->has_scene = true;
     return RT_OK;
 }
@@ -418,6 +421,7 @@ int32_t rt_update_objects(rt_ctx *c, uint32_t first, uint32_t count, const rt_ob
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, hipMemcpy(c->objects.ptr + first, objs.data(), (size_t)count * sizeof(DevObject), hipMemcpyHostToDevice));
     std::copy(objects, objects + count, c->h_objects.begin() + first);
+    c->scene_serial += 1u;
     if (c->scene.bvh_nodes) return upload_hierarchy(c);  // moved objects: new boxes
     return RT_OK;
 }
@@ -470,6 +474,7 @@ int32_t rt_set_camera(rt_ctx *c, const rt_camera_desc *cam) {
     hipLaunchKernelGGL(rt_raygen_kernel, dim3((cam->width + 63u) / 64u, (cam->height + 3u) / 4u), dim3(256), 0, c->stream, C, c->ray_dirs.ptr);
     RT_HIP(c, hipGetLastError());
     RT_HIP(c, hipStreamSynchronize(c->stream));   // renders may be launched on other streams
+    c->scene_serial += 1u;
     c->has_camera = true;
     return RT_OK;
 }
@@ -540,10 +545,14 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         grid = dim3(std::min<uint32_t>(c->wf_groups, W.tiles_x * W.tiles_y));
         blocks = grid.x;
         RT_HIP(c, c->wf_pool.ensure((size_t)c->wf_groups * kWfPool * 4u));   // four float4 planes per pool entry
-        RT_HIP(c, c->wf_ctrl.ensure(16));
+        RT_HIP(c, c->wf_ctrl.ensure(2u + (size_t)tiles_y));
+        {   // the per-row costs only describe a launch over the same rows of the same frame
+            const uint64_t key = ((uint64_t)c->camera.width << 40) ^ ((uint64_t)c->camera.height << 20) ^ ((uint64_t)rb << 44) ^ ((uint64_t)re << 8) ^ stride ^ ((uint64_t)c->scene_serial << 52);
+            if (key != c->wf_order_key) { RT_HIP(c, hipMemsetAsync(c->wf_ctrl.ptr, 0, (2u + (size_t)tiles_y) * sizeof(uint32_t), s)); c->wf_order_key = key; }
+        }
         const size_t plane = (size_t)c->wf_groups * kWfPool;
         W.a = c->wf_pool.ptr; W.b = W.a + plane; W.c = W.b + plane; W.d = W.c + plane;
-        W.tile_counter = c->wf_ctrl.ptr;
+        W.ctrl = c->wf_ctrl.ptr;
     }
     const uint32_t ncnt = (events ? (uint32_t)RT_CNT_COUNT : 0u) + 1u;
     uint32_t *counters = nullptr;
@@ -575,7 +584,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
     const bool time_kernel = p->no_timing == 0;
     if (time_kernel) RT_HIP(c, hipEventRecord(c->ev0, s));
     if (regroup) {
-        RT_HIP(c, hipMemsetAsync(W.tile_counter, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(rt_wf_order_kernel, dim3(1), dim3(256), 0, s, W.ctrl, W.tiles_y);
 #ifdef RT_WF_STATS
         static unsigned long long *s_wfstats = nullptr;
         if (!s_wfstats) (void)hipMalloc((void **)&s_wfstats, 2 * WS_N * sizeof(unsigned long long));
