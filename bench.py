@@ -81,6 +81,8 @@ def main() -> None:
     ap.add_argument("--workload", default="scene3_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--shard", default=None, choices=["frames", "rows", "samples"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--keep-accum-store", action="store_true",
+                    help="non-accumulating workloads: also write the frame's linear value to the accumulator (default: RT_RENDER_SKIP_ACCUM_STORE)")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -151,9 +153,14 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Non-accumulating frames: nothing reads Renderer.accumulated (src/renderer.rs:67-68 writes it, no caller of render() reads
+    # it), so the frame's linear value is not written to it: 4 instead of 20 bytes stored per pixel.  The parity tests keep it.
+    skip_store = not args.keep_accum_store
+
     def render(sample_index: int, acc: bool = accumulate, rows=rows_arg, events: bool = False) -> None:
         # the timed region is bracketed by this script's own events, so the library's per-launch timing events are off
         ctx.render_device(frame_index=sample_index if acc else 1, accumulate=acc, seed=0x5EED,
+                          flags=pkg.RT_RENDER_SKIP_ACCUM_STORE if (skip_store and not acc) else 0,
                           rows=(rows[0], rows[1]) if rows else None, tile_row_stride=rows[2] if rows else 0,
                           d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh, no_timing=not events, collect_events=events)
 
@@ -272,6 +279,7 @@ def main() -> None:
             "config": {"workload": f"{args.workload}: {description}", "width": width, "height": height,
                        "max_ray_bounces": int(scene.desc.max_ray_bounces), "samples_per_step": spp,
                        "rays_per_step_per_rank": int(rays_rank), "sharding": shard, "clock_prewarm_ms": int(CLOCK_PREWARM_S * 1e3),
+                       "accumulator_store": "n/a (accumulating)" if accumulate or shard == "samples" else ("skipped" if skip_store else "written"),
                        "ranks": world, "backend": backend if use_dist else "none", "exchange_ms_per_step": round(exchange_ms, 4),
                        "collective": ("none" if shard in ("none", "frames") or not xch.collectives else
                                       "all_gather(rgba8 tile rows)" if shard == "rows" else
@@ -292,7 +300,7 @@ def main() -> None:
             # the secondary bound: measured HBM bytes of one launch over the launch time, against the 8 TB/s HBM3E peak, and
             # against the bytes the frame has to move at the least (4 B RGBA8 per pixel; 36 B when accumulating)
             gbps = traffic / (kernel_ms * 1e-3) / 1e9
-            alg = width * height * (36 if accumulate else 4)
+            alg = width * height * (36 if (accumulate or shard == "samples") else 4)
             out["roofline"]["hbm_view"] = {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
                                            "algorithmic_bytes": alg, "traffic_over_algorithmic": round(traffic / alg, 2)}
         if scene.desc.ray_marching:

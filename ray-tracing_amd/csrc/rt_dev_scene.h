@@ -109,6 +109,7 @@ struct DevFrame {
     uint32_t tile_row_step;  // rows between the starts of consecutive tile rows of this launch: 8, or 8 N for an interleaved share
     uint32_t leaf_slots;  // march kernel: object-space rays cached in LDS (0: none)
     int32_t accumulate;
+    int32_t skip_accum_store;  // accumulate == 0 only: do not write the frame's linear value to the accumulator
     uint64_t seed;
     uint32_t *rgba;      // width*height packed R | G<<8 | B<<16 | A<<24
     float *accum;        // width*height float4

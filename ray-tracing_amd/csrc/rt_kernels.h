@@ -579,8 +579,10 @@ RT_DEV void store_pixel(const DevFrame &F, uint32_t pos, f3 p) {
         c.x = rt_clamp01_sse(p.x); c.y = rt_clamp01_sse(p.y); c.z = rt_clamp01_sse(p.z); c.w = rt_clamp01_sse(1.0f);
         // written once and not read again by this launch: streamed past the caches, which keeps textures, hierarchy nodes and
         // object records resident (the four stores merge into one 16-byte store)
-        __builtin_nontemporal_store(c.x, &acc->x); __builtin_nontemporal_store(c.y, &acc->y);
-        __builtin_nontemporal_store(c.z, &acc->z); __builtin_nontemporal_store(c.w, &acc->w);
+        if (!F.skip_accum_store) {   // wave-uniform
+            __builtin_nontemporal_store(c.x, &acc->x); __builtin_nontemporal_store(c.y, &acc->y);
+            __builtin_nontemporal_store(c.z, &acc->z); __builtin_nontemporal_store(c.w, &acc->w);
+        }
     }
     uint32_t r = rt_as_u8(c.x * 255.0f), g = rt_as_u8(c.y * 255.0f), b = rt_as_u8(c.z * 255.0f), a8 = rt_as_u8(c.w + 255.0f);
     __builtin_nontemporal_store(r | (g << 8) | (b << 16) | (a8 << 24), &F.rgba[pos]);

@@ -123,6 +123,15 @@ int32_t fail(rt_ctx *c, rt_status st, const std::string &msg) {
     if (c) c->err = msg;
     return (int32_t)st;
 }
+// Nothing may be thrown across the C boundary: every entry point that can allocate host memory runs inside
+// RT_GUARD_BEGIN / RT_GUARD_END, which turn an exception (std::bad_alloc from a vector or string) into RT_ERR_DEVICE.
+int32_t guard_fail(rt_ctx *c) {
+    if (c) { try { c->err = "out of host memory (or another C++ exception) inside the library"; } catch (...) { } }
+    return (int32_t)RT_ERR_DEVICE;
+}
+#define RT_GUARD_BEGIN try {
+#define RT_GUARD_END(ctx) } catch (...) { return guard_fail(ctx); }
+
 #define RT_HIP(ctx, call)                                                                                   \
     do {                                                                                                    \
         hipError_t e_ = (call);                                                                             \
@@ -229,6 +238,7 @@ void launch(K kernel, dim3 grid, uint32_t threads, size_t lds, hipStream_t s, co
 // Scenes with many bounded objects get a bounding-volume hierarchy; small scenes keep the reference's linear scan.
 // Built from the context's host copy of the objects (again after rt_update_objects moved some of them).
 int32_t upload_hierarchy(rt_ctx *c) {
+    RT_GUARD_BEGIN
     DevScene &S = c->scene;
     S.bvh_nodes = nullptr; S.unbounded = nullptr; S.n_bvh_nodes = 0; S.n_unbounded = 0;
     S.bvh2_nodes = nullptr; S.bvh2_linear = nullptr; S.n_bvh2_linear = 0;
@@ -258,6 +268,7 @@ int32_t upload_hierarchy(rt_ctx *c) {
         }
     }
     return RT_OK;
+    RT_GUARD_END(c)
 }
 
 }  // namespace
@@ -269,6 +280,7 @@ int32_t rt_abi_version(void) { return RT_ABI_VERSION; }
 const char *rt_last_error(rt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int32_t rt_create(int32_t device_id, rt_ctx **out) {
+    RT_GUARD_BEGIN
     if (!out) return RT_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     int n = 0;
@@ -288,6 +300,7 @@ int32_t rt_create(int32_t device_id, rt_ctx **out) {
     }
     *out = c;
     return RT_OK;
+    RT_GUARD_END(nullptr)
 }
 
 void rt_destroy(rt_ctx *c) {
@@ -308,6 +321,7 @@ void rt_destroy(rt_ctx *c) {
 }
 
 int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
+    RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!d) return fail(c, RT_ERR_INVALID_ARGUMENT, "scene is null");
     if ((d->n_objects && !d->objects) || (d->n_materials && !d->materials) || (d->n_lights && !d->lights) || (d->n_sdfs && !d->sdfs))
@@ -340,6 +354,9 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     if (d->ray_marching && d->n_sdfs > 0 && d->n_materials == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "ray marching scene without materials");
 
     RT_HIP(c, hipSetDevice(c->device));
+    // from here on the context's scene is being replaced: it counts as "not set" until every step below has succeeded, so a
+    // failure in between can never leave a render launching on freed or half-updated buffers
+    c->has_scene = false;
     std::vector<DevObject> objs(d->n_objects);
     for (uint32_t i = 0; i < d->n_objects; i++) objs[i] = make_dev_object(d->objects[i]);
     std::vector<DevMaterial> mats(d->n_materials);
@@ -396,9 +413,11 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     c->scene_serial += 1u;
     c->has_scene = true;
     return RT_OK;
+    RT_GUARD_END(c)
 }
 
 int32_t rt_update_objects(rt_ctx *c, uint32_t first, uint32_t count, const rt_object *objects) {
+    RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!c->has_scene) return fail(c, RT_ERR_STATE, "scene not set");
     if (count == 0) return RT_OK;
@@ -419,14 +438,18 @@ int32_t rt_update_objects(rt_ctx *c, uint32_t first, uint32_t count, const rt_ob
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, wait_external(c, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->has_scene = false;   // set again once the device copy and the hierarchies are consistent
     RT_HIP(c, hipMemcpy(c->objects.ptr + first, objs.data(), (size_t)count * sizeof(DevObject), hipMemcpyHostToDevice));
     std::copy(objects, objects + count, c->h_objects.begin() + first);
     c->scene_serial += 1u;
-    if (c->scene.bvh_nodes) return upload_hierarchy(c);  // moved objects: new boxes
+    if (c->scene.bvh_nodes) { int32_t r = upload_hierarchy(c); if (r != RT_OK) return r; }  // moved objects: new boxes
+    c->has_scene = true;
     return RT_OK;
+    RT_GUARD_END(c)
 }
 
 int32_t rt_set_texture(rt_ctx *c, uint32_t index, uint32_t width, uint32_t height, const uint8_t *rgb8) {
+    RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (index >= kMaxTextures) return fail(c, RT_ERR_UNSUPPORTED, "texture slot above 63");
     if (!rgb8 || width == 0 || height == 0 || width > 32768 || height > 32768) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad texture arguments");
@@ -443,13 +466,16 @@ int32_t rt_set_texture(rt_ctx *c, uint32_t index, uint32_t width, uint32_t heigh
     c->h_textures[index].height = height;
     RT_HIP(c, hipMemcpy(c->textures.ptr + index, &c->h_textures[index], sizeof(DevTexture), hipMemcpyHostToDevice));
     return RT_OK;
+    RT_GUARD_END(c)
 }
 
 int32_t rt_set_camera(rt_ctx *c, const rt_camera_desc *cam) {
+    RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!cam || cam->width == 0 || cam->height == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad camera");
     if ((uint64_t)cam->width * cam->height > (1ull << 31)) return fail(c, RT_ERR_UNSUPPORTED, "frame above 2^31 pixels");
     RT_HIP(c, hipSetDevice(c->device));
+    c->has_camera = false;   // until the buffers and the direction table below are in place
     DevCamera &C = c->camera;
     for (int r = 0; r < 4; r++) {
         C.ip_c0[r] = cam->inverse_perspective[r]; C.ip_c1[r] = cam->inverse_perspective[4 + r];
@@ -477,9 +503,11 @@ int32_t rt_set_camera(rt_ctx *c, const rt_camera_desc *cam) {
     c->scene_serial += 1u;
     c->has_camera = true;
     return RT_OK;
+    RT_GUARD_END(c)
 }
 
 int32_t rt_reset_accum(rt_ctx *c) {
+    RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!c->has_camera) return fail(c, RT_ERR_STATE, "camera not set");
     RT_HIP(c, hipSetDevice(c->device));
@@ -487,6 +515,7 @@ int32_t rt_reset_accum(rt_ctx *c) {
     RT_HIP(c, hipMemsetAsync(c->accum.ptr, 0, (size_t)c->camera.width * c->camera.height * 4 * sizeof(float), c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     return RT_OK;
+    RT_GUARD_END(c)
 }
 
 }  // extern "C"
@@ -496,6 +525,7 @@ namespace {
 // One frame into device buffers.  `noalloc`: the launch's counter rows go to the file-scope `scratch` array instead of a
 // block grown with hipMalloc, and launches that would need more than it holds are refused.
 int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d_accum, void *stream, bool noalloc) {
+    RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!p) return fail(c, RT_ERR_INVALID_ARGUMENT, "params is null");
     if (!c->has_scene || !c->has_camera) return fail(c, RT_ERR_STATE, "scene or camera not set");
@@ -567,6 +597,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
 
     DevFrame F;
     F.frame_index = p->frame_index; F.row_begin = rb; F.row_end = re; F.tile_row_step = 8u * stride; F.leaf_slots = 0; F.accumulate = p->accumulate; F.seed = p->seed;
+    F.skip_accum_store = (!p->accumulate && (p->flags & RT_RENDER_SKIP_ACCUM_STORE)) ? 1 : 0;
     F.rgba = d_rgba8 ? (uint32_t *)d_rgba8 : c->rgba.ptr;
     F.accum = d_accum ? (float *)d_accum : c->accum.ptr;
     F.counters = counters;
@@ -602,7 +633,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         }
 #endif
     } else if (S.ray_marching) {
-        // up to 16 leaves (48 KiB of LDS per workgroup) keep their object-space rays in LDS during the march loop
+        // up to 16 leaves (12.5 KiB of LDS per 64-thread workgroup) keep their object-space rays in LDS during the march loop
         const bool cache = c->leaf_slots >= 1u && c->leaf_slots <= (uint32_t)RT_MARCH_CACHE_MAX_SLOTS;
         F.leaf_slots = cache ? c->leaf_slots : 0u;
         const size_t lds = cache ? (size_t)c->leaf_slots * 3u * (threads + 1u) * sizeof(float) : 0u;
@@ -648,6 +679,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
 #endif
     c->frames += 1;
     return RT_OK;
+    RT_GUARD_END(c)
 }
 
 }  // namespace
@@ -663,6 +695,7 @@ int32_t rt_render_device_noalloc(rt_ctx *c, const rt_render_params *p, void *d_r
 }
 
 int32_t rt_resolve_device(rt_ctx *c, uint32_t sample_count, uint32_t row_begin, uint32_t row_end, void *d_accum, void *d_rgba8, void *stream) {
+    RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!c->has_camera) return fail(c, RT_ERR_STATE, "camera not set");
     if (sample_count == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "sample_count must be >= 1");
@@ -677,9 +710,11 @@ int32_t rt_resolve_device(rt_ctx *c, uint32_t sample_count, uint32_t row_begin, 
                        (uint32_t *)(d_rgba8 ? d_rgba8 : (void *)c->rgba.ptr), first, count, (float)sample_count);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
+    RT_GUARD_END(c)
 }
 
 int32_t rt_render(rt_ctx *c, uint32_t frame_index, int32_t accumulate, int32_t reset_accum, uint64_t seed, uint8_t *out, size_t out_len) {
+    RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!c->has_scene || !c->has_camera) return fail(c, RT_ERR_STATE, "scene or camera not set");
     const size_t need = (size_t)c->camera.width * c->camera.height * 4;
@@ -697,9 +732,11 @@ int32_t rt_render(rt_ctx *c, uint32_t frame_index, int32_t accumulate, int32_t r
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->evc0, c->evc1) == hipSuccess) c->last_copy_ms = ms;
     return RT_OK;
+    RT_GUARD_END(c)
 }
 
 int32_t rt_alloc_host_frame(rt_ctx *c, size_t len, void **out_ptr) {
+    RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!out_ptr || len == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "out_ptr is null or len is 0");
     *out_ptr = nullptr;
@@ -709,9 +746,11 @@ int32_t rt_alloc_host_frame(rt_ctx *c, size_t len, void **out_ptr) {
     c->pinned.emplace_back(p, len);
     *out_ptr = p;
     return RT_OK;
+    RT_GUARD_END(c)
 }
 
 int32_t rt_free_host_frame(rt_ctx *c, void *ptr) {
+    RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     for (size_t i = 0; i < c->pinned.size(); i++) {
         if (c->pinned[i].first != ptr) continue;
@@ -722,9 +761,11 @@ int32_t rt_free_host_frame(rt_ctx *c, void *ptr) {
         return RT_OK;
     }
     return fail(c, RT_ERR_INVALID_ARGUMENT, "pointer was not returned by rt_alloc_host_frame of this context");
+    RT_GUARD_END(c)
 }
 
 int32_t rt_read_accum(rt_ctx *c, float *out, size_t n_vec4) {
+    RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!c->has_camera) return fail(c, RT_ERR_STATE, "camera not set");
     if (!out || n_vec4 != (size_t)c->camera.width * c->camera.height) return fail(c, RT_ERR_INVALID_ARGUMENT, "out must hold width*height float4");
@@ -733,18 +774,22 @@ int32_t rt_read_accum(rt_ctx *c, float *out, size_t n_vec4) {
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, hipMemcpy(out, c->accum.ptr, n_vec4 * 4 * sizeof(float), hipMemcpyDeviceToHost));
     return RT_OK;
+    RT_GUARD_END(c)
 }
 
 int32_t rt_read_ray_directions(rt_ctx *c, float *out, size_t n_vec3) {
+    RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!c->has_camera) return fail(c, RT_ERR_STATE, "camera not set");
     if (!out || n_vec3 != (size_t)c->camera.width * c->camera.height) return fail(c, RT_ERR_INVALID_ARGUMENT, "out must hold width*height directions");
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipMemcpy(out, c->ray_dirs.ptr, n_vec3 * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return RT_OK;
+    RT_GUARD_END(c)
 }
 
 int32_t rt_get_stats(rt_ctx *c, rt_stats *out) {
+    RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!out) return fail(c, RT_ERR_INVALID_ARGUMENT, "out is null");
     std::memset(out, 0, sizeof(*out));
@@ -765,6 +810,7 @@ int32_t rt_get_stats(rt_ctx *c, rt_stats *out) {
     out->last_copy_ms = c->last_copy_ms;
     out->frames_rendered = c->frames;
     return RT_OK;
+    RT_GUARD_END(c)
 }
 
 void *rt_context_stream(rt_ctx *c) { return c ? (void *)c->stream : nullptr; }

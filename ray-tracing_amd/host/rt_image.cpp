@@ -89,6 +89,8 @@ bool decode_png(const std::vector<uint8_t> &file, Texture &t, std::string &err) 
 
     const size_t bits_per_pixel = (size_t)channels * depth, stride = ((size_t)w * bits_per_pixel + 7) / 8;
     const size_t bpp = bits_per_pixel >= 8 ? bits_per_pixel / 8 : 1;   // filter distance in bytes
+    // the header alone decides this allocation: refuse images whose decoded rows exceed 1 GiB before allocating anything
+    if ((stride + 1) > ((size_t)1 << 30) / h) { err = "PNG larger than 1 GiB when decoded"; return false; }
     std::vector<uint8_t> raw((stride + 1) * h);
     uLongf raw_len = (uLongf)raw.size();
     int z = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());

@@ -269,6 +269,31 @@ def test_page_locked_host_frame_receives_the_same_bytes(pkg, ctx):
     assert l.rt_alloc_host_frame(ctx._ctx, 0, C.byref(C.c_void_p())) == -1
 
 
+@pytest.mark.parametrize("name", ["scene3", "scene4"])
+def test_skipping_the_accumulator_store_changes_no_pixel(pkg, ctx, name):
+    """RT_RENDER_SKIP_ACCUM_STORE: a non-accumulating frame leaves the accumulator alone and writes the same bytes; an
+    accumulating frame ignores the flag."""
+    import torch
+    s = pkg.Scene(name)
+    w, h = 200, 120
+    ctx.load(s, w, h)
+    rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    accum = torch.full((h, w, 4), 7.0, dtype=torch.float32, device="cuda")
+    ctx.render_device(frame_index=1, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), flags=pkg.RT_RENDER_SKIP_ACCUM_STORE)
+    ctx.stats()
+    assert bool((accum == 7.0).all()), "the accumulator was written"
+    ref_rgba = torch.zeros_like(rgba)
+    ref_acc = torch.zeros_like(accum)
+    ctx.render_device(frame_index=1, d_rgba8=ref_rgba.data_ptr(), d_accum=ref_acc.data_ptr())
+    ctx.stats()
+    assert torch.equal(rgba, ref_rgba) and not bool((ref_acc == 7.0).any())
+    a = torch.zeros_like(accum); b = torch.zeros_like(accum)
+    ctx.render_device(frame_index=1, accumulate=True, d_rgba8=rgba.data_ptr(), d_accum=a.data_ptr(), flags=pkg.RT_RENDER_SKIP_ACCUM_STORE)
+    ctx.render_device(frame_index=1, accumulate=True, d_rgba8=rgba.data_ptr(), d_accum=b.data_ptr())
+    ctx.stats()
+    assert torch.equal(a, b) and float(a[..., 3].min()) == 1.0
+
+
 def test_launch_without_timing_events_renders_the_same_frame(pkg, ctx):
     """rt_render_params.no_timing: the launch is not bracketed by timing events; the frame and the ray count are unchanged and
     rt_stats.last_kernel_ms reads 0 until a timed launch follows."""
