@@ -290,7 +290,7 @@ def main() -> None:
                          # the 157.3 TFLOP/s peak is one FMA (2 flops) per lane every 2 cycles; bit-exact parity keeps multiplies
                          # and adds unfused, so one flop per lane-instruction (half of it) bounds this code
                          "frac_of_unfused_peak": round(achieved / (FP32_VALU_PEAK_TFLOPS / 2.0), 5),
-                         "kernel": "rt_march_kernel" if scene.desc.ray_marching else "rt_trace_kernel",
+                         "kernel": kernel_name(pkg, scene),
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
                          "note": "FP32 vector (VALU) roofline: this path has no dense contraction, so no MFMA"},
         }
@@ -314,6 +314,18 @@ def main() -> None:
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_name(pkg, scene) -> str:
+    """The kernel rt_render_device launches for this scene (the choice in ray-tracing_amd/csrc/rt_mi355x.hip)."""
+    d = scene.desc
+    if d.ray_marching:
+        return "rt_march_kernel"
+    refractive = any(d.materials[i].kind == pkg.RT_REFRACTIVE for i in range(d.n_materials))
+    bounded = sum(1 for i in range(d.n_objects) if d.objects[i].kind not in (pkg.RT_PLANE, pkg.RT_UNION, pkg.RT_SUBSTRACTION))
+    if d.diffuse and not refractive and bounded >= 32 and d.max_ray_bounces >= 1:
+        return "rt_wf_diffuse_kernel"
+    return "rt_trace_kernel"
 
 
 def file_sha256(path: str) -> str:

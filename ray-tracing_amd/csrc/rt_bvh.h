@@ -270,6 +270,8 @@ inline void rt_bvh2_build(const rt_scene_desc *d, RtBvh2 &out) {
     }
     std::sort(out.linear.begin(), out.linear.end());
     if (ids.size() < 2) return;
+    // a balanced tree over this many objects must fit the traversal stack, or the depth limit could not be kept
+    if (RtBvhBuilder::ceil_log2((uint32_t)ids.size()) + 1u > kBvh2MaxDepth) return;
     B.ids = ids;
     B.build(0, (uint32_t)B.ids.size());
     // quantisation grid over the root box: q in [3, 65532] for coordinates inside it, so that the outward rounding below

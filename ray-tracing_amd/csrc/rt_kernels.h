@@ -637,8 +637,11 @@ enum { FK_REFL = 0, FK_REFR1 = 1, FK_REFR2 = 2, FK_PASS = 3 };
 // tex4 -2.6 %, scene2 -2.5 %, scene3 -0.3 %; 8 waves spill heavily, +50 %).  Variants with refractive frames: 6 waves
 // (80 VGPRs; 5 or 4 waves measured slower).  Hierarchy variants: the 96 registers of 5 waves (5 % faster than 6).
 // The march kernel below fits 8 waves per SIMD (64 VGPRs).
+#ifndef RT_REFR_WAVES
+#define RT_REFR_WAVES 6
+#endif
 template <bool EVENTS, bool REFR, int RDEPTH, bool BVH>
-__global__ void __launch_bounds__(256, BVH ? 5 : (REFR ? 6 : 7)) rt_trace_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
+__global__ void __launch_bounds__(256, BVH ? 5 : (REFR ? RT_REFR_WAVES : 7)) rt_trace_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
     extern __shared__ float s_frames[];
     __shared__ uint32_t s_cnt[(EVENTS ? RT_CNT_COUNT : 0) + 1];
     __shared__ __attribute__((aligned(16))) double s_pow[RT_POW_LDS_DOUBLES];

@@ -647,7 +647,11 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
     } else {
         const size_t lds = (size_t)(maxd ? maxd : 1u) * 4u * threads * sizeof(float);
         // kernel variant: bit 0 events, bits 1-2 refractive frames (0 none, 1 up to 8, 2 up to 32), bit 3 hierarchy
+#ifdef RT_FORCE_REFR   // experiment: the variant with refractive frames on scenes that have no refractive material
+        const int rsel = maxd <= 8u ? 1 : 2;
+#else
         const int rsel = !c->has_refractive ? 0 : (maxd <= 8u ? 1 : 2);
+#endif
         const int variant = (events ? 1 : 0) | (rsel << 1) | (S.bvh_nodes ? 8 : 0);
         switch (variant) {
 #define RT_CASE(V, E, R, D, B) case V: launch(rt_trace_kernel<E, R, D, B>, grid, threads, lds, s, S, c->camera, F); break;
