@@ -303,6 +303,18 @@ int32_t rt_read_accum(rt_ctx *ctx, float *out_vec4, size_t n_vec4);
  * fills the device table (Camera::calculate_ray_directions, src/camera.rs:128-157); frames only read it. */
 int32_t rt_read_ray_directions(rt_ctx *ctx, float *out_vec3, size_t n_vec3);
 
+/* What rt_set_scene built for the current scene (no counterpart in the reference, which scans all objects linearly).
+ * Scenes with fewer than 32 bounded objects have no hierarchy: every count is 0. */
+typedef struct rt_hierarchy_info {
+    uint32_t stackless_nodes;    /* nodes of one layout of the skip-link hierarchy (one-lane-per-pixel kernels)              */
+    uint32_t stackless_linear;   /* objects outside it, tested linearly (planes)                                           */
+    uint32_t two_child_nodes;    /* nodes of the quantised two-child hierarchy; 0 unless the scene is diffuse without glass */
+    uint32_t two_child_linear;   /* objects outside it: planes and objects too large for its 16-bit grid                   */
+    uint32_t regrouping_kernel;  /* 1: rt_render_device traces this scene with the kernel that re-groups rays between bounces */
+    uint32_t reserved[3];
+} rt_hierarchy_info;
+int32_t rt_get_hierarchy_info(rt_ctx *ctx, rt_hierarchy_info *out);
+
 /* Waits for the context's stream and sums the per-workgroup counters of the last render. */
 int32_t rt_get_stats(rt_ctx *ctx, rt_stats *out);
 

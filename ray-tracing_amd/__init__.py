@@ -117,6 +117,11 @@ class rt_stats(C.Structure):
                 ("last_copy_ms", C.c_double), ("frames_rendered", C.c_uint64)]
 
 
+class rt_hierarchy_info(C.Structure):
+    _fields_ = [("stackless_nodes", C.c_uint32), ("stackless_linear", C.c_uint32), ("two_child_nodes", C.c_uint32),
+                ("two_child_linear", C.c_uint32), ("regrouping_kernel", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
 class rt_render_params(C.Structure):
     _fields_ = [("frame_index", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("accumulate", C.c_int32),
                 ("collect_events", C.c_int32), ("no_timing", C.c_int32), ("seed", C.c_uint64),
@@ -128,7 +133,7 @@ ABI_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_texture", "rt_set_camera", "rt_render", "rt_render_device",
     "rt_resolve_device", "rt_reset_accum", "rt_read_accum", "rt_get_stats", "rt_context_stream", "rt_device_rgba8", "rt_device_accum", "rt_last_error",
     "rt_abi_version", "rt_alloc_host_frame", "rt_free_host_frame", "rt_update_objects", "rt_read_ray_directions",
-    "rt_render_device_noalloc",
+    "rt_render_device_noalloc", "rt_get_hierarchy_info",
 ]
 
 # RT_MI355X_LIB overrides the library file (used to A/B kernel builds); it is still a HIP build of this backend
@@ -168,6 +173,7 @@ def lib() -> C.CDLL:
         l.rt_alloc_host_frame.argtypes = [vp, C.c_size_t, C.POINTER(C.c_void_p)]; l.rt_alloc_host_frame.restype = C.c_int32
         l.rt_free_host_frame.argtypes = [vp, C.c_void_p]; l.rt_free_host_frame.restype = C.c_int32
         l.rt_get_stats.argtypes = [vp, C.POINTER(rt_stats)]; l.rt_get_stats.restype = C.c_int32
+        l.rt_get_hierarchy_info.argtypes = [vp, C.POINTER(rt_hierarchy_info)]; l.rt_get_hierarchy_info.restype = C.c_int32
         l.rt_context_stream.argtypes = [vp]; l.rt_context_stream.restype = vp
         l.rt_device_rgba8.argtypes = [vp]; l.rt_device_rgba8.restype = vp
         l.rt_device_accum.argtypes = [vp]; l.rt_device_accum.restype = vp
@@ -410,6 +416,12 @@ class Context:
         d["last_copy_ms"] = float(s.last_copy_ms)
         d["frames_rendered"] = int(s.frames_rendered)
         return d
+
+    def hierarchy_info(self) -> dict:
+        """rt_get_hierarchy_info: node and linear-object counts of the hierarchies built for the current scene."""
+        h = rt_hierarchy_info()
+        self._check(self._l.rt_get_hierarchy_info(self._ctx, C.byref(h)), "rt_get_hierarchy_info")
+        return {k: int(getattr(h, k)) for k, _ in rt_hierarchy_info._fields_ if k != "reserved"}
 
     def device_rgba8(self) -> int:
         return int(self._l.rt_device_rgba8(self._ctx) or 0)

@@ -102,6 +102,7 @@ struct rt_ctx {
     DevBuf<float4> wf_pool;       // ray pools of the re-grouping path tracer: wf_groups x kWfPool entries of 3.5 float4
     DevBuf<uint32_t> wf_ctrl;     // its tile counter
     uint32_t wf_groups = 0;       // persistent single-wave workgroups that fit the device (0: not queried yet)
+    size_t n_bvh2_nodes = 0;      // nodes of the quantised two-child hierarchy of the current scene
     uint64_t wf_order_key = 0;    // frame / row range the tile-row costs in wf_ctrl belong to
     uint32_t scene_serial = 0;    // bumped by rt_set_scene, rt_update_objects and rt_set_camera
     DevBuf<uint32_t> counters;
@@ -264,6 +265,7 @@ int32_t upload_hierarchy(rt_ctx *c) {
             RT_HIP(c, hipMemcpy(c->bvh2_nodes.ptr, b2.nodes.data(), b2.nodes.size() * sizeof(DevBvh2Node), hipMemcpyHostToDevice));
             if (!b2.linear.empty()) RT_HIP(c, hipMemcpy(c->bvh2_linear.ptr, b2.linear.data(), b2.linear.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             S.bvh2_nodes = c->bvh2_nodes.ptr; S.bvh2_linear = c->bvh2_linear.ptr; S.n_bvh2_linear = (uint32_t)b2.linear.size();
+            c->n_bvh2_nodes = b2.nodes.size();
             for (int k = 0; k < 3; k++) { S.bvh2_origin[k] = b2.origin[k]; S.bvh2_scale[k] = b2.scale[k]; }
         }
     }
@@ -815,6 +817,20 @@ int32_t rt_get_stats(rt_ctx *c, rt_stats *out) {
     out->frames_rendered = c->frames;
     return RT_OK;
     RT_GUARD_END(c)
+}
+
+int32_t rt_get_hierarchy_info(rt_ctx *c, rt_hierarchy_info *out) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!out) return fail(c, RT_ERR_INVALID_ARGUMENT, "out is null");
+    if (!c->has_scene) return fail(c, RT_ERR_STATE, "scene not set");
+    std::memset(out, 0, sizeof(*out));
+    const DevScene &S = c->scene;
+    out->stackless_nodes = S.bvh_nodes ? S.n_bvh_nodes : 0u;
+    out->stackless_linear = S.bvh_nodes ? S.n_unbounded : 0u;
+    out->two_child_nodes = S.bvh2_nodes ? (uint32_t)c->n_bvh2_nodes : 0u;
+    out->two_child_linear = S.bvh2_nodes ? S.n_bvh2_linear : 0u;
+    out->regrouping_kernel = (!S.ray_marching && S.bvh2_nodes && S.diffuse && !c->has_refractive && S.max_ray_bounces >= 1u) ? 1u : 0u;
+    return RT_OK;
 }
 
 void *rt_context_stream(rt_ctx *c) { return c ? (void *)c->stream : nullptr; }

@@ -762,6 +762,75 @@ def test_random_scenes_through_the_hierarchy(pkg, orc, ctx, seed):
     assert np.array_equal(ctx.read_accum().view(np.uint32), lin.view(np.uint32))
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_diffuse_scenes_through_the_regrouping_path_tracer(pkg, orc, ctx, seed):
+    """Random diffuse (emissive) scenes of 40-90 objects of every primitive kind, rotated and overlapping, with exact
+    duplicates (equal distances), planes and a very large sphere (both outside the quantised hierarchy, in its linear
+    list), textured materials, 1-6 bounces, a ragged frame size: the re-grouping kernel (the default for such scenes),
+    the one-lane-per-pixel kernel and the oracle's linear scan agree bit for bit over three accumulated samples."""
+    import torch
+    rng = np.random.default_rng(9000 + seed)
+    mats = [make_material(pkg, albedo=tuple(rng.uniform(0.2, 0.9, 3)), roughness=float(rng.uniform(0.1, 1.0)),
+                          emission_power=float(rng.choice([0.0, 0.0, 0.8, 3.0]))) for _ in range(6)]
+    mats.append(make_material(pkg, albedo=(0.5, 0.5, 0.5), texture=int(rng.integers(0, 4)), roughness=0.7))
+    mats.append(make_material(pkg, albedo=(0.5, 0.5, 0.5), texture=int(rng.integers(0, 4)), roughness=0.9, emission_power=1.5))
+    objs = [make_object(pkg, pkg.RT_PLANE, int(rng.integers(0, 8)), normal=(0, 1, 0), point=(0, -0.6, 0), max_dist=(9.0, 9.0), has_max_dist=seed % 2)]
+    if seed % 3 != 2:   # a sphere 200 times larger than everything else: an outlier of the quantisation grid
+        objs.append(make_object(pkg, pkg.RT_SPHERE, int(rng.integers(0, 6)), position=(0.0, -201.0 + float(rng.uniform(0, 0.3)), 0.0), radius=200.0))
+    if seed % 4 == 1:
+        objs.append(make_object(pkg, pkg.RT_PLANE, int(rng.integers(0, 8)), normal=(0, 0, 1), point=(0, 0, -9)))
+    n = int(rng.integers(40, 90))
+    for i in range(n):
+        pos = (float(rng.uniform(-5, 5)), float(rng.uniform(-0.3, 2.5)), float(rng.uniform(-7, 2)))
+        rot = tuple(float(a) for a in rng.uniform(-180, 180, 3))
+        m = int(rng.integers(0, 8))
+        kind = int(rng.integers(0, 5))
+        if i > 0 and i % 13 == 0:
+            objs.append(pkg.rt_object.from_buffer_copy(objs[-1]))
+        elif kind == 0:
+            objs.append(make_object(pkg, pkg.RT_SPHERE, m, position=pos, rotation_axis=rot, radius=float(rng.uniform(0.2, 0.9))))
+        elif kind == 1:
+            objs.append(make_object(pkg, pkg.RT_CUBOID, m, position=pos, rotation_axis=rot, dimension=tuple(float(a) for a in rng.uniform(0.15, 0.7, 3))))
+        elif kind == 2:
+            objs.append(make_object(pkg, pkg.RT_CYLINDER, m, position=pos, rotation_axis=rot, radius=0.3, height=1.0))
+        elif kind == 3:
+            objs.append(make_object(pkg, pkg.RT_CONE, m, position=pos, rotation_axis=rot, radius=float(rng.uniform(0.2, 0.6)), height=float(rng.uniform(0.4, 1.2))))
+        else:
+            v1 = np.array(pos)
+            objs.append(make_object(pkg, pkg.RT_TRIANGLE, m, v1=tuple(v1), v2=tuple(v1 + rng.uniform(-1.2, 1.2, 3)), v3=tuple(v1 + rng.uniform(-1.2, 1.2, 3))))
+    sb = SceneBuilder(pkg, objs, mats, (), n_textures=4, max_ray_bounces=int(rng.integers(1, 7)), diffuse=1,
+                      ambient_color=(0.3, 0.5, 0.8))
+    w, h = int(rng.integers(100, 150)), int(rng.integers(60, 100))
+    cam = pkg.make_camera((float(rng.uniform(-2, 2)), float(rng.uniform(0.8, 3)), float(rng.uniform(4, 8))), (float(rng.uniform(-0.2, 0.2)), -0.2, -1.0), w, h)
+    tex = pkg.load_textures()
+    for i, t in enumerate(tex):
+        ctx.set_texture(i, t)
+    ctx.set_scene(sb.desc)
+    ctx.set_camera(cam)
+    info = ctx.hierarchy_info()
+    n_planes = sum(1 for o in objs if o.kind == pkg.RT_PLANE)
+    assert info["regrouping_kernel"] == 1 and info["two_child_nodes"] > 30 and info["stackless_linear"] == n_planes
+    assert info["two_child_linear"] == n_planes + (1 if seed % 3 != 2 else 0), "planes and the very large sphere are tested linearly"
+    acc = np.zeros((h, w, 4), dtype=np.float32)
+    bufs = {}
+    for flags in (0, pkg.RT_RENDER_ONE_LANE_PER_PIXEL):
+        rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        rays = 0
+        for f in (1, 2, 3):
+            ctx.render_device(frame_index=f, accumulate=True, seed=31 + seed, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), flags=flags)
+            rays += ctx.stats()["rays_total"]
+        bufs[flags] = (rgba.cpu().numpy(), accum.cpu().numpy(), rays)
+    ref = None
+    ref_rays = 0
+    for f in (1, 2, 3):
+        ref = orc.render(sb.desc, cam, tex, frame_index=f, accumulate=True, seed=31 + seed, accum=acc, n_threads=8, want_counters=True)
+        ref_rays += sum(ref["counters"][:5])
+    for flags, (rgba, accum, rays) in bufs.items():
+        assert_parity(rgba, ref["rgba"], accum, acc, what=f"random diffuse scene {seed}, flags {flags}")
+        assert rays == ref_rays
+
+
 @pytest.mark.parametrize("seed", list(range(6)))
 def test_random_scenes_in_the_random_number_modes(pkg, orc, ctx, seed):
     """Diffuse path tracing and the roughness-jitter mode on random small scenes (emissive, glass and plain materials),
