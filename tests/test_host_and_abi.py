@@ -215,7 +215,7 @@ def test_host_load_image_refuses_what_it_cannot_decode_exactly(pkg, tmp_path):
 def test_committed_bench_line_carries_the_contract_fields():
     """The benchmark line kept under profiles/ (printed by bench.py on the GPU box) has the fields the harness reads."""
     import json
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench_default.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_bench_scene3_4k.json")
     d = json.loads(open(path).read().strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -224,6 +224,8 @@ def test_committed_bench_line_carries_the_contract_fields():
     assert "scene3" in d["config"]["workload"] and d["config"]["width"] == 3840 and d["config"]["height"] == 2160
     r = d["roofline"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["traffic"] > 0 and r["unit"] == "TFLOP/s"
+    # measured HBM bytes against the bytes the frame has to move at the least (4 B of RGBA8 per pixel, non-accumulating)
+    assert r["hbm_view"]["algorithmic_bytes"] == 3840 * 2160 * 4 and abs(r["hbm_view"]["traffic_over_algorithmic"] - r["traffic"] / r["hbm_view"]["algorithmic_bytes"]) < 0.01
     # the whole-job rate is the ray count of one step over the step time
     assert abs(d["value"] - d["config"]["rays_per_step_per_rank"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
     c = d["cpu_baseline"]
