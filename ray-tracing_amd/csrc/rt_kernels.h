@@ -215,7 +215,8 @@ RT_DEV int test_slot(int kind) {
 
 // RayTracing::trace_ray (src/ray_tracing/ray_tracing.rs:59-78): linear scan, accept 0 < t < closest (strict),
 // so the lowest index wins ties.  Returns the object index or -1.
-template <bool EVENTS>
+// SP: the host has checked that every object of the scene is a sphere or a plane; the other candidate tests are left out.
+template <bool EVENTS, bool SP = false>
 RT_DEV int trace_closest(const DevScene &S, f3 ro, f3 rd, float &t_out, int &sub_out, Cnt<EVENTS> &cnt, int ray_slot) {
     const uint32_t n = S.n_objects;
     if (n == 0u) return -1;
@@ -244,11 +245,11 @@ RT_DEV int trace_closest(const DevScene &S, f3 ro, f3 rd, float &t_out, int &sub
         bool ok = false;
         switch (o.kind) {
             case RT_SPHERE: cnt.add(RT_CNT_TEST_SPHERE); ok = cand_sphere(o, ro, rd, t); break;
-            case RT_TRIANGLE: cnt.add(RT_CNT_TEST_TRIANGLE); ok = cand_triangle(o, ro, rd, t); break;
-            case RT_CUBOID: cnt.add(RT_CNT_TEST_CUBOID); ok = cand_cuboid(o, ro, rd, t); break;
+            case RT_TRIANGLE: if (!SP) { cnt.add(RT_CNT_TEST_TRIANGLE); ok = cand_triangle(o, ro, rd, t); } break;
+            case RT_CUBOID: if (!SP) { cnt.add(RT_CNT_TEST_CUBOID); ok = cand_cuboid(o, ro, rd, t); } break;
             case RT_PLANE: cnt.add(RT_CNT_TEST_PLANE); ok = cand_plane(o, ro, rd, t); break;
-            case RT_CYLINDER: cnt.add(RT_CNT_TEST_CYLINDER); ok = cand_cylinder(o, ro, rd, t, sub); break;
-            case RT_CONE: cnt.add(RT_CNT_TEST_CONE); ok = cand_cone(o, ro, rd, t, sub); break;
+            case RT_CYLINDER: if (!SP) { cnt.add(RT_CNT_TEST_CYLINDER); ok = cand_cylinder(o, ro, rd, t, sub); } break;
+            case RT_CONE: if (!SP) { cnt.add(RT_CNT_TEST_CONE); ok = cand_cone(o, ro, rd, t, sub); } break;
             default: break;  // Union / Substraction: Ray::hit's `_ => None` (src/ray.rs:175)
         }
         if (ok && t > 0.0f && t < closest) { closest = t; best = (int)i; best_sub = sub; }
@@ -320,10 +321,10 @@ RT_DEV int trace_closest_bvh(const DevScene &S, f3 ro, f3 rd, float &t_out, int 
     return best;
 }
 
-template <bool EVENTS, bool BVH>
+template <bool EVENTS, bool BVH, bool SP = false>
 RT_DEV int trace_ray(const DevScene &S, f3 ro, f3 rd, float &t_out, int &sub_out, Cnt<EVENTS> &cnt, int ray_slot) {
     if (BVH) return trace_closest_bvh<EVENTS>(S, ro, rd, t_out, sub_out, cnt, ray_slot);
-    return trace_closest<EVENTS>(S, ro, rd, t_out, sub_out, cnt, ray_slot);
+    return trace_closest<EVENTS, SP>(S, ro, rd, t_out, sub_out, cnt, ray_slot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -409,10 +410,15 @@ RT_DEV void fin_triangle(const DevObject &o, f3 ro, f3 rd, float t, HitRec &h) {
     h.normal = normalize(sign * n);
 }
 
-template <bool EVENTS>
+template <bool EVENTS, bool SP = false>
 RT_DEV void finalize_one(const DevObject &o, const DevMaterial &dm, f3 ro, f3 rd, float t, int sub, HitRec &h, Mtl &m, Cnt<EVENTS> &cnt) {
     m = load_mtl(dm);
     const bool need_uv = dm.texture >= 0 && dm.kind == RT_REFLECTIVE;
+    if (SP) {
+        if (o.kind == RT_SPHERE) { cnt.add(RT_CNT_HIT_SPHERE); fin_sphere(o, ro, rd, t, need_uv, h); }
+        else { cnt.add(RT_CNT_HIT_PLANE); fin_plane(o, ro, rd, t, h); }
+        return;
+    }
     switch (o.kind) {
         case RT_SPHERE: cnt.add(RT_CNT_HIT_SPHERE); fin_sphere(o, ro, rd, t, need_uv, h); break;
         case RT_TRIANGLE: cnt.add(RT_CNT_HIT_TRIANGLE); fin_triangle(o, ro, rd, t, h); break;
@@ -426,7 +432,7 @@ RT_DEV void finalize_one(const DevObject &o, const DevMaterial &dm, f3 ro, f3 rd
 // Completes the closest hit of every lane.  Small scenes: lanes of a wave usually share a handful of winners, so the
 // loop visits each distinct winner once with a wave-uniform object (scalar loads, no divergent switch).  Large scenes
 // (BVH): winners are mostly distinct, so every lane loads its own object.
-template <bool EVENTS, bool BVH>
+template <bool EVENTS, bool BVH, bool SP = false>
 RT_DEV void finalize_hit(const DevScene &S, f3 ro, f3 rd, float t, int obj, int sub, HitRec &h, Mtl &m, Cnt<EVENTS> &cnt) {
     h.u = 0.0f; h.v = 0.0f;
     if (BVH) {
@@ -439,7 +445,7 @@ RT_DEV void finalize_hit(const DevScene &S, f3 ro, f3 rd, float t, int obj, int 
         int cur = __builtin_amdgcn_readfirstlane(pending);
         if (pending == cur) {
             const DevObject &o = S.objects[cur];
-            finalize_one<EVENTS>(o, S.materials[o.material], ro, rd, t, sub, h, m, cnt);
+            finalize_one<EVENTS, SP>(o, S.materials[o.material], ro, rd, t, sub, h, m, cnt);
             break;
         }
     }
@@ -471,7 +477,7 @@ RT_DEV void light_dir_dist(const DevLight &l, f3 point, f3 &dir, float &dist) {
 // halves the sum if the shadow ray towards it hits another object.  Every halving is the same exact operation (x 0.5),
 // so only their number matters: one loop shades a light and traces its shadow ray (its direction is computed once),
 // and the halvings are applied after the loop.
-template <bool EVENTS, bool BVH>
+template <bool EVENTS, bool BVH, bool SP = false>
 RT_DEV f3 shade_lights(const DevScene &S, f3 ray_dir, const HitRec &h, f3 albedo, const Mtl &m, int obj_index, PowTab pow_tab, Cnt<EVENTS> &cnt DG_ARG) {
     cnt.add(RT_CNT_LIGHT_CALL);
     f3 l_acc = splat3(0.0f);
@@ -491,7 +497,7 @@ RT_DEV f3 shade_lights(const DevScene &S, f3 ray_dir, const HitRec &h, f3 albedo
         if (shadows) {
             float st; int ssub;
             DG_BEGIN(DG_SHADOW_TRACE)
-            int idx = trace_ray<EVENTS, BVH>(S, so, -ldir, st, ssub, cnt, RT_CNT_RAYS_SHADOW);
+            int idx = trace_ray<EVENTS, BVH, SP>(S, so, -ldir, st, ssub, cnt, RT_CNT_RAYS_SHADOW);
             DG_END(DG_SHADOW_TRACE)
             if (idx >= 0 && idx != obj_index) occluded += 1u;
         }
@@ -631,16 +637,19 @@ enum { FK_REFL = 0, FK_REFR1 = 1, FK_REFR2 = 2, FK_PASS = 3 };
 //   REFR   : the scene has refractive materials (two-child frames are compiled in)
 //   RDEPTH : capacity of the per-lane refractive frame array (>= max_ray_bounces when REFR)
 //   BVH    : closest hits go through the bounding-volume hierarchy (scenes with many objects)
+//   SP     : every object is a sphere or a plane (the reference's default scene): the other four primitives' candidate
+//            tests and hit completions are compiled out (scene3 4K: 0.101 -> 0.096 ms); never combined with BVH
 //   dynamic LDS: max_ray_bounces * 4 * blockDim.x floats (reflective frames, one column per lane)
 // ------------------------------------------------------------------------------------------------
 // second launch bound = waves per SIMD.  Plain variant: 7 waves (72 VGPRs, 16 bytes of spills; measured against 6 waves:
 // tex4 -2.6 %, scene2 -2.5 %, scene3 -0.3 %; 8 waves spill heavily, +50 %).  Variants with refractive frames: 6 waves
 // (80 VGPRs; 5 or 4 waves measured slower).  Hierarchy variants: the 96 registers of 5 waves (5 % faster than 6).
+// The spheres-and-planes variant at 8 waves (64 VGPRs, 16 bytes of spills) measured 5 % slower than at 7.
 // The march kernel below fits 8 waves per SIMD (64 VGPRs).
 #ifndef RT_REFR_WAVES
 #define RT_REFR_WAVES 6
 #endif
-template <bool EVENTS, bool REFR, int RDEPTH, bool BVH>
+template <bool EVENTS, bool REFR, int RDEPTH, bool BVH, bool SP = false>
 __global__ void __launch_bounds__(256, BVH ? 5 : (REFR ? RT_REFR_WAVES : 7)) rt_trace_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
     extern __shared__ float s_frames[];
     __shared__ uint32_t s_cnt[(EVENTS ? RT_CNT_COUNT : 0) + 1];
@@ -688,7 +697,7 @@ __global__ void __launch_bounds__(256, BVH ? 5 : (REFR ? RT_REFR_WAVES : 7)) rt_
             } else {
                 float t; int sub;
                 DG_BEGIN(DG_TRACE)
-                int obj = trace_ray<EVENTS, BVH>(S, ro, rd, t, sub, cnt, ray_slot);
+                int obj = trace_ray<EVENTS, BVH, SP>(S, ro, rd, t, sub, cnt, ray_slot);
                 DG_END(DG_TRACE)
                 if (obj < 0) {
                     V = L + ambient * Cc;
@@ -696,7 +705,7 @@ __global__ void __launch_bounds__(256, BVH ? 5 : (REFR ? RT_REFR_WAVES : 7)) rt_
                 } else {
                     HitRec h; Mtl m;
                     DG_BEGIN(DG_FINALIZE)
-                    finalize_hit<EVENTS, BVH>(S, ro, rd, t, obj, sub, h, m, cnt);
+                    finalize_hit<EVENTS, BVH, SP>(S, ro, rd, t, obj, sub, h, m, cnt);
                     DG_END(DG_FINALIZE)
                     f3 albedo = m.albedo;
                     if (m.kind == RT_REFLECTIVE) {
@@ -705,7 +714,7 @@ __global__ void __launch_bounds__(256, BVH ? 5 : (REFR ? RT_REFR_WAVES : 7)) rt_
                         DG_END(DG_TEX)
                         f3 p;
                         DG_BEGIN(DG_LIGHTS)
-                        if (!dmode) p = shade_lights<EVENTS, BVH>(S, rd, h, albedo, m, obj, s_pow, cnt DG_PASS);
+                        if (!dmode) p = shade_lights<EVENTS, BVH, SP>(S, rd, h, albedo, m, obj, s_pow, cnt DG_PASS);
                         else p = L + m.emission_power * albedo;
                         DG_END(DG_LIGHTS)
                         cnt.add(scene_diffuse ? RT_CNT_DIFFUSE_RAY : RT_CNT_REFLECTION_RAY);
@@ -734,7 +743,7 @@ __global__ void __launch_bounds__(256, BVH ? 5 : (REFR ? RT_REFR_WAVES : 7)) rt_
                         f3 lo = h.point + RT_EPSILON * h.normal;
                         f3 ldv = rt_reflect(rd, h.normal);
                         f3 p;
-                        if (!dmode) p = shade_lights<EVENTS, BVH>(S, rd, h, albedo, m, obj, s_pow, cnt DG_PASS);
+                        if (!dmode) p = shade_lights<EVENTS, BVH, SP>(S, rd, h, albedo, m, obj, s_pow, cnt DG_PASS);
                         else p = L + m.emission_power * albedo;
                         f3 cchild = Cc * albedo;
                         float *f = rfr[depth];

@@ -94,6 +94,7 @@ struct rt_ctx {
     DevScene scene = {};
     DevCamera camera = {};
     bool has_scene = false, has_camera = false, has_refractive = false;
+    bool spheres_planes_only = false;   // every object of the scene is a sphere or a plane: kernels without the other primitives
     uint32_t leaf_slots = 0;  // ray-marching scenes: leaves per sdfs() call with an object-space ray
 
     DevBuf<uint32_t> rgba;
@@ -361,6 +362,9 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     c->has_scene = false;
     std::vector<DevObject> objs(d->n_objects);
     for (uint32_t i = 0; i < d->n_objects; i++) objs[i] = make_dev_object(d->objects[i]);
+    c->spheres_planes_only = d->n_objects > 0;
+    for (uint32_t i = 0; i < d->n_objects; i++)
+        if (d->objects[i].kind != RT_SPHERE && d->objects[i].kind != RT_PLANE) c->spheres_planes_only = false;
     std::vector<DevMaterial> mats(d->n_materials);
     c->mat_texture.assign(d->n_materials, -1);
     c->has_refractive = false;
@@ -648,15 +652,20 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         }
     } else {
         const size_t lds = (size_t)(maxd ? maxd : 1u) * 4u * threads * sizeof(float);
-        // kernel variant: bit 0 events, bits 1-2 refractive frames (0 none, 1 up to 8, 2 up to 32), bit 3 hierarchy
+        // kernel variant: bit 0 events, bits 1-2 refractive frames (0 none, 1 up to 8, 2 up to 32), bit 3 hierarchy,
+        // bit 4 spheres and planes only (timed variants without hierarchy)
 #ifdef RT_FORCE_REFR   // experiment: the variant with refractive frames on scenes that have no refractive material
         const int rsel = maxd <= 8u ? 1 : 2;
 #else
         const int rsel = !c->has_refractive ? 0 : (maxd <= 8u ? 1 : 2);
 #endif
-        const int variant = (events ? 1 : 0) | (rsel << 1) | (S.bvh_nodes ? 8 : 0);
+        const bool sp = c->spheres_planes_only && !events && !S.bvh_nodes;
+        const int variant = (events ? 1 : 0) | (rsel << 1) | (S.bvh_nodes ? 8 : 0) | (sp ? 16 : 0);
         switch (variant) {
 #define RT_CASE(V, E, R, D, B) case V: launch(rt_trace_kernel<E, R, D, B>, grid, threads, lds, s, S, c->camera, F); break;
+            case 16: launch(rt_trace_kernel<false, false, 1, false, true>, grid, threads, lds, s, S, c->camera, F); break;
+            case 18: launch(rt_trace_kernel<false, true, 8, false, true>, grid, threads, lds, s, S, c->camera, F); break;
+            case 20: launch(rt_trace_kernel<false, true, 32, false, true>, grid, threads, lds, s, S, c->camera, F); break;
             RT_CASE(0, false, false, 1, false) RT_CASE(1, true, false, 1, false)
             RT_CASE(2, false, true, 8, false) RT_CASE(3, true, true, 8, false)
             RT_CASE(4, false, true, 32, false) RT_CASE(5, true, true, 32, false)
