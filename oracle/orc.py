@@ -44,6 +44,8 @@ def load(host_libm: bool = False) -> C.CDLL:
             getattr(l, f).argtypes = [C.c_float, C.c_float]; getattr(l, f).restype = C.c_float
         for f in ("orc_atanf_det", "orc_atanf_host"):
             getattr(l, f).argtypes = [C.c_float]; getattr(l, f).restype = C.c_float
+        l.orc_powf_det_array.argtypes = [vp, vp, vp, C.c_size_t]; l.orc_powf_det_array.restype = None
+        l.orc_atanf_det_array.argtypes = [vp, vp, C.c_size_t]; l.orc_atanf_det_array.restype = None
         l.orc_rng_path_key.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]; l.orc_rng_path_key.restype = C.c_uint32
         l.orc_rng_child_key.argtypes = [C.c_uint32, C.c_uint32]; l.orc_rng_child_key.restype = C.c_uint32
         l.orc_rng_uniform.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_float]; l.orc_rng_uniform.restype = C.c_float

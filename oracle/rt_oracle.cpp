@@ -947,6 +947,8 @@ void orc_texture_from_uv(const orc_texture *tex, float u, float v, float rgb[3])
 float orc_powf_det(float x, float y) { return orc_powf_spec(x, y); }
 float orc_atanf_det(float x) { return orc_atanf_spec(x); }
 float orc_powf_host(float x, float y) { return ::powf(x, y); }
+void orc_powf_det_array(const float *x, const float *y, float *out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = orc_powf_spec(x[i], y[i]); }
+void orc_atanf_det_array(const float *x, float *out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = orc_atanf_spec(x[i]); }
 float orc_atanf_host(float x) { return ::atanf(x); }
 
 uint32_t orc_rng_path_key(uint64_t seed, uint32_t pixel_index, uint32_t frame_index) { return rng_path_key(seed, pixel_index, frame_index); }

@@ -73,6 +73,9 @@ float orc_powf_det(float x, float y);
 float orc_atanf_det(float x);
 float orc_powf_host(float x, float y);
 float orc_atanf_host(float x);
+/* The deterministic pair over arrays: out[i] = powf(x[i], y[i]) / atanf(x[i]). */
+void orc_powf_det_array(const float *x, const float *y, float *out, size_t n);
+void orc_atanf_det_array(const float *x, float *out, size_t n);
 
 /* The counter-based generator standing in for ThreadRng: uniform f32 in [low, high) drawn as
  * rand 0.8.5 maps a u32 (Cargo.lock:671-683): (bits >> 9) * 2^-23 * (high - low) + low. */

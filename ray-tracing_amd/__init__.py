@@ -30,6 +30,7 @@ REPO_ROOT = os.path.dirname(_HERE)
 RT_SPHERE, RT_TRIANGLE, RT_CUBOID, RT_PLANE, RT_CYLINDER, RT_CONE, RT_UNION, RT_SUBSTRACTION = range(8)
 RT_REFLECTIVE, RT_REFRACTIVE = 0, 1
 RT_DIRECTIONAL, RT_POSITIONAL, RT_SPHERICAL_POSITIONAL = 0, 1, 2
+RT_MATH_POWF, RT_MATH_ATANF = 0, 1
 RT_RENDER_ONE_LANE_PER_PIXEL, RT_RENDER_SKIP_ACCUM_STORE = 1, 2
 
 COUNTER_NAMES = [
@@ -133,7 +134,7 @@ ABI_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_texture", "rt_set_camera", "rt_render", "rt_render_device",
     "rt_resolve_device", "rt_reset_accum", "rt_read_accum", "rt_get_stats", "rt_context_stream", "rt_device_rgba8", "rt_device_accum", "rt_last_error",
     "rt_abi_version", "rt_alloc_host_frame", "rt_free_host_frame", "rt_update_objects", "rt_read_ray_directions",
-    "rt_render_device_noalloc", "rt_get_hierarchy_info",
+    "rt_render_device_noalloc", "rt_get_hierarchy_info", "rt_eval_math",
 ]
 
 # RT_MI355X_LIB overrides the library file (used to A/B kernel builds); it is still a HIP build of this backend
@@ -174,6 +175,7 @@ def lib() -> C.CDLL:
         l.rt_free_host_frame.argtypes = [vp, C.c_void_p]; l.rt_free_host_frame.restype = C.c_int32
         l.rt_get_stats.argtypes = [vp, C.POINTER(rt_stats)]; l.rt_get_stats.restype = C.c_int32
         l.rt_get_hierarchy_info.argtypes = [vp, C.POINTER(rt_hierarchy_info)]; l.rt_get_hierarchy_info.restype = C.c_int32
+        l.rt_eval_math.argtypes = [vp, C.c_int32, C.c_size_t, vp, vp, vp]; l.rt_eval_math.restype = C.c_int32
         l.rt_context_stream.argtypes = [vp]; l.rt_context_stream.restype = vp
         l.rt_device_rgba8.argtypes = [vp]; l.rt_device_rgba8.restype = vp
         l.rt_device_accum.argtypes = [vp]; l.rt_device_accum.restype = vp
@@ -422,6 +424,17 @@ class Context:
         h = rt_hierarchy_info()
         self._check(self._l.rt_get_hierarchy_info(self._ctx, C.byref(h)), "rt_get_hierarchy_info")
         return {k: int(getattr(h, k)) for k, _ in rt_hierarchy_info._fields_ if k != "reserved"}
+
+    def eval_math(self, op: int, x: np.ndarray, y: np.ndarray = None) -> np.ndarray:
+        """rt_eval_math: the kernels' powf(x, y) (op RT_MATH_POWF) or atanf(x) (op RT_MATH_ATANF), evaluated on the device."""
+        x = np.ascontiguousarray(x, dtype=np.float32).ravel()
+        if y is not None:
+            y = np.ascontiguousarray(y, dtype=np.float32).ravel()
+            if y.size != x.size:
+                raise ValueError("x and y must have the same number of elements")
+        out = np.empty_like(x)
+        self._check(self._l.rt_eval_math(self._ctx, op, x.size, x.ctypes.data, y.ctypes.data if y is not None else None, out.ctypes.data), "rt_eval_math")
+        return out
 
     def device_rgba8(self) -> int:
         return int(self._l.rt_device_rgba8(self._ctx) or 0)

@@ -803,6 +803,40 @@ int32_t rt_read_ray_directions(rt_ctx *c, float *out, size_t n_vec3) {
     RT_GUARD_END(c)
 }
 
+// One lane per element; the same inlined rt_powf / rt_atanf as the render kernels, tables staged in LDS the same way.
+__global__ void __launch_bounds__(256) rt_math_kernel(int op, size_t n, const float *x, const float *y, float *out) {
+    __shared__ __attribute__((aligned(16))) double s_pow[RT_POW_LDS_DOUBLES];
+    rt_pow_lds_init(s_pow);
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = op == RT_MATH_POWF ? rt_powf(x[i], y[i], s_pow) : rt_atanf(x[i]);
+}
+
+int32_t rt_eval_math(rt_ctx *c, int32_t op, size_t n, const float *x, const float *y, float *out) {
+    RT_GUARD_BEGIN
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (op != RT_MATH_POWF && op != RT_MATH_ATANF) return fail(c, RT_ERR_INVALID_ARGUMENT, "unknown math op");
+    if (n == 0) return RT_OK;
+    if (!x || !out || (op == RT_MATH_POWF && !y)) return fail(c, RT_ERR_INVALID_ARGUMENT, "null operand array");
+    RT_HIP(c, hipSetDevice(c->device));
+    float *d = nullptr;   // x | y | out
+    RT_HIP(c, hipMalloc(&d, 3 * n * sizeof(float)));
+    hipError_t e = hipMemcpy(d, x, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && op == RT_MATH_POWF) e = hipMemcpy(d + n, y, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const size_t want = (n + 255) / 256;
+        const unsigned blocks = (unsigned)(want < 65536 ? want : 65536);
+        hipLaunchKernelGGL(rt_math_kernel, dim3(blocks), dim3(256), 0, c->stream, (int)op, n, (const float *)d, (const float *)(d + n), d + 2 * n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    RT_HIP(c, e);
+    return RT_OK;
+    RT_GUARD_END(c)
+}
+
 int32_t rt_get_stats(rt_ctx *c, rt_stats *out) {
     RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
