@@ -18,6 +18,10 @@ torch.distributed.run it is one of the ranks.  The frame is split the way the re
            reduce-scatter(sum) of the accumulators, resolve of the owned rows, one all-gather of RGBA8 bands per frame.
   frames   (opt-in) whole frames of a sequence per rank, no collective.
 The timing is barrier + synchronize on both sides and the maximum over ranks.  Rank 0 prints one JSON line.
+
+Without --workload the line is the default workload's, and a short second measurement (2 steps) of BASELINE.json's
+multi-GPU configuration -- the 8K / 10 000-sphere / 64-spp frame, sharded by sample index when N > 1 -- rides along under
+the key "config5" (--no-config5 leaves it out), so that one run per GPU count tells how that frame scales as well.
 """
 from __future__ import annotations
 
@@ -78,12 +82,17 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default: 1000 frames (5 for the 64-spp workload)")
     ap.add_argument("--warmup", type=int, default=None, help="default: 20 frames (1 for the 64-spp workload)")
-    ap.add_argument("--workload", default="scene3_4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: scene3_4k (BASELINE configs[1]), followed by a short config-5 measurement")
     ap.add_argument("--shard", default=None, choices=["frames", "rows", "samples"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="default workload only: without the ride-along measurement of the 8K / 10 000-sphere / 64-spp frame")
     ap.add_argument("--keep-accum-store", action="store_true",
                     help="non-accumulating workloads: also write the frame's linear value to the accumulator (default: RT_RENDER_SKIP_ACCUM_STORE)")
     args = ap.parse_args()
+    with_config5 = args.workload is None and not args.no_config5 and args.shard in (None, "samples")
+    if args.workload is None:
+        args.workload = "scene3_4k"
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -126,191 +135,211 @@ def main() -> None:
     torch.cuda.set_device(device_index)
 
     pkg = graft.load_package()
-    scene_name, width, height, bounces, accumulate, spp, multi_shard, description = WORKLOADS[args.workload]
-    # a 4K frame takes 0.1-1 ms: 1000 timed frames take at most a second
-    if args.steps is None:
-        args.steps = 1000 if spp == 1 else 5
-    if args.warmup is None:
-        args.warmup = 20 if spp == 1 else 1
-    shard = args.shard or (multi_shard if use_dist else "none")
-    if shard == "samples" and spp == 1:
-        sys.exit("bench.py: --shard samples needs a multi-sample workload (spheres10k_8k)")
-    scene = pkg.Scene(scene_name)
-    if bounces is not None:
-        scene.desc.max_ray_bounces = bounces
-    ctx = pkg.Context(device_index)
-    ctx.load(scene, width, height)
 
-    # every buffer a step touches exists before the timed loop: frame, accumulator, and the collectives' send/receive blocks
-    xch = pkg.FrameExchange(dist, height, width, rank, world, device="cuda", backend=backend, force_collectives=use_dist)
-    rgba, accum = xch.frame, xch.accum
-    stream = torch.cuda.current_stream()
-    sh = stream.cuda_stream
-    rows_arg = xch.render_rows() if (shard == "rows" and xch.collectives) else None
+    def measure(workload: str, steps, warmup, want_cpu_baseline: bool, shard_arg):
+        """One workload through warm-up and K timed steps; rank 0 gets the result line as a dict, the others None."""
+        scene_name, width, height, bounces, accumulate, spp, multi_shard, description = WORKLOADS[workload]
+        # a 4K frame takes 0.1-1 ms: 1000 timed frames take at most a second
+        if steps is None:
+            steps = 1000 if spp == 1 else 5
+        if warmup is None:
+            warmup = 20 if spp == 1 else 1
+        shard = shard_arg or (multi_shard if use_dist else "none")
+        if shard == "samples" and spp == 1:
+            sys.exit("bench.py: --shard samples needs a multi-sample workload (spheres10k_8k)")
+        scene = pkg.Scene(scene_name)
+        if bounces is not None:
+            scene.desc.max_ray_bounces = bounces
+        ctx = pkg.Context(device_index)
+        ctx.load(scene, width, height)
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+        # every buffer a step touches exists before the timed loop: frame, accumulator, and the collectives' send/receive blocks
+        xch = pkg.FrameExchange(dist, height, width, rank, world, device="cuda", backend=backend, force_collectives=use_dist)
+        rgba, accum = xch.frame, xch.accum
+        stream = torch.cuda.current_stream()
+        sh = stream.cuda_stream
+        rows_arg = xch.render_rows() if (shard == "rows" and xch.collectives) else None
 
-    # Non-accumulating frames: nothing reads Renderer.accumulated (src/renderer.rs:67-68 writes it, no caller of render() reads
-    # it), so the frame's linear value is not written to it: 4 instead of 20 bytes stored per pixel.  The parity tests keep it.
-    skip_store = not args.keep_accum_store
+        def barrier():
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    def render(sample_index: int, acc: bool = accumulate, rows=rows_arg, events: bool = False) -> None:
-        # the timed region is bracketed by this script's own events, so the library's per-launch timing events are off
-        ctx.render_device(frame_index=sample_index if acc else 1, accumulate=acc, seed=0x5EED,
-                          flags=pkg.RT_RENDER_SKIP_ACCUM_STORE if (skip_store and not acc) else 0,
-                          rows=(rows[0], rows[1]) if rows else None, tile_row_stride=rows[2] if rows else 0,
-                          d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh, no_timing=not events, collect_events=events)
+        # Non-accumulating frames: nothing reads Renderer.accumulated (src/renderer.rs:67-68 writes it, no caller of render() reads
+        # it), so the frame's linear value is not written to it: 4 instead of 20 bytes stored per pixel.  The parity tests keep it.
+        skip_store = not args.keep_accum_store
 
-    def sample_ids(i: int):
-        if shard == "samples":
-            return pkg.shard_samples(spp, rank, world, 1 + i * spp)
-        if shard == "frames":
-            return [1 + (i * world + rank) * spp + k for k in range(spp)]
-        return [1 + i * spp + k for k in range(spp)]
+        def render(sample_index: int, acc: bool = accumulate, rows=rows_arg, events: bool = False) -> None:
+            # the timed region is bracketed by this script's own events, so the library's per-launch timing events are off
+            ctx.render_device(frame_index=sample_index if acc else 1, accumulate=acc, seed=0x5EED,
+                              flags=pkg.RT_RENDER_SKIP_ACCUM_STORE if (skip_store and not acc) else 0,
+                              rows=(rows[0], rows[1]) if rows else None, tile_row_stride=rows[2] if rows else 0,
+                              d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh, no_timing=not events, collect_events=events)
 
-    kernel_events, exchange_events = [], []
+        def sample_ids(i: int):
+            if shard == "samples":
+                return pkg.shard_samples(spp, rank, world, 1 + i * spp)
+            if shard == "frames":
+                return [1 + (i * world + rank) * spp + k for k in range(spp)]
+            return [1 + i * spp + k for k in range(spp)]
 
-    def step(i: int, timed: bool = False) -> None:
-        # per-step events only where a step has collectives to separate from the render launches (an event pair costs
-        # several microseconds on the stream: too much for a 0.1 ms frame); otherwise one pair brackets the timed loop
-        timed = timed and xch.collectives and shard in ("rows", "samples")
-        if timed:
-            k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            k0.record(stream)
-        if shard == "samples":
-            accum.zero_()
-        for idx in sample_ids(i):
-            render(idx, acc=True if shard == "samples" else accumulate)
-        if timed:
-            k1.record(stream)
-            kernel_events.append((k0, k1))
-        if shard in ("none", "frames") or not xch.collectives:
-            return
-        if shard == "rows":
-            xch.gather_interleaved()
-        else:
-            # a reduce-scatter leaves each rank with the summed rows it owns; it resolves them (divide, clamp, pack) and the
-            # RGBA8 bands are all-gathered
-            rb, re, band = xch.sum_accumulators()
-            if xch.reduce_scatter:
-                ctx.resolve_device(spp, rows=(0, re - rb), d_accum=band.data_ptr(), d_rgba8=xch.band_rgba.data_ptr(), stream=sh)
+        kernel_events, exchange_events = [], []
+
+        def step(i: int, timed: bool = False) -> None:
+            # per-step events only where a step has collectives to separate from the render launches (an event pair costs
+            # several microseconds on the stream: too much for a 0.1 ms frame); otherwise one pair brackets the timed loop
+            timed = timed and xch.collectives and shard in ("rows", "samples")
+            if timed:
+                k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                k0.record(stream)
+            if shard == "samples":
+                accum.zero_()
+            for idx in sample_ids(i):
+                render(idx, acc=True if shard == "samples" else accumulate)
+            if timed:
+                k1.record(stream)
+                kernel_events.append((k0, k1))
+            if shard in ("none", "frames") or not xch.collectives:
+                return
+            if shard == "rows":
+                xch.gather_interleaved()
             else:
-                ctx.resolve_device(spp, rows=(rb, re), d_accum=accum.data_ptr(), d_rgba8=rgba.data_ptr(), stream=sh)
-            xch.gather_bands(rb, re)
-        if timed:
-            x1 = torch.cuda.Event(enable_timing=True)
-            x1.record(stream)
-            exchange_events.append((k1, x1))
+                # a reduce-scatter leaves each rank with the summed rows it owns; it resolves them (divide, clamp, pack) and the
+                # RGBA8 bands are all-gathered
+                rb, re, band = xch.sum_accumulators()
+                if xch.reduce_scatter:
+                    ctx.resolve_device(spp, rows=(0, re - rb), d_accum=band.data_ptr(), d_rgba8=xch.band_rgba.data_ptr(), stream=sh)
+                else:
+                    ctx.resolve_device(spp, rows=(rb, re), d_accum=accum.data_ptr(), d_rgba8=rgba.data_ptr(), stream=sh)
+                xch.gather_bands(rb, re)
+            if timed:
+                x1 = torch.cuda.Event(enable_timing=True)
+                x1.record(stream)
+                exchange_events.append((k1, x1))
 
-    # The GPU raises its clock over the first ~50 ms of sustained work (measured: a scene3 frame goes from 0.125 ms to a steady
-    # 0.104 ms over the first 500 frames).  Render untimed frames for that long before the warm-up steps, so that the timed
-    # steps see the steady clock whatever --warmup says.  With collectives in the step every rank must run the same number of
-    # steps, so there the pre-warm is a fixed count.
-    if not xch.collectives or shard in ("none", "frames"):
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < CLOCK_PREWARM_S:
-            for _ in range(8 if spp == 1 else 1):
+        # The GPU raises its clock over the first ~50 ms of sustained work (measured: a scene3 frame goes from 0.125 ms to a steady
+        # 0.104 ms over the first 500 frames).  Render untimed frames for that long before the warm-up steps, so that the timed
+        # steps see the steady clock whatever --warmup says.  With collectives in the step every rank must run the same number of
+        # steps, so there the pre-warm is a fixed count.
+        if not xch.collectives or shard in ("none", "frames"):
+            t_pre = time.perf_counter()
+            while time.perf_counter() - t_pre < CLOCK_PREWARM_S:
+                for _ in range(8 if spp == 1 else 1):
+                    step(0)
+                torch.cuda.synchronize()
+        else:
+            for _ in range(200 if spp == 1 else 1):
                 step(0)
             torch.cuda.synchronize()
-    else:
-        for _ in range(200 if spp == 1 else 1):
-            step(0)
-        torch.cuda.synchronize()
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for i in range(args.steps):
-        step(args.warmup + i, timed=True)
-    ev1.record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    launches_per_step = len(sample_ids(0))
-    # average launch duration of the render kernel(s), from events on the launch stream: around each step's render launches
-    # when the step also has collectives, around the whole timed loop (launches back to back) otherwise
-    if kernel_events:
-        kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / (args.steps * launches_per_step)
-    else:
-        kernel_ms = ev0.elapsed_time(ev1) / (args.steps * launches_per_step)
-    exchange_ms = sum(a.elapsed_time(b) for a, b in exchange_events) / args.steps if exchange_events else 0.0
-    # rays per step: deterministic scenes trace the same rays every frame; random modes vary by < 0.1 % between sample sets,
-    # so the count of the first timed step's sample set stands for every step (untimed pass: one stats read-back per render)
-    rays_rank = 0
-    for idx in sample_ids(args.warmup):
-        render(idx, acc=True if shard == "samples" else accumulate)
-        rays_rank += ctx.stats()["rays_total"]
+        for i in range(warmup):
+            step(i)
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for i in range(steps):
+            step(warmup + i, timed=True)
+        ev1.record(stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        launches_per_step = len(sample_ids(0))
+        # average launch duration of the render kernel(s), from events on the launch stream: around each step's render launches
+        # when the step also has collectives, around the whole timed loop (launches back to back) otherwise
+        if kernel_events:
+            kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / (steps * launches_per_step)
+        else:
+            kernel_ms = ev0.elapsed_time(ev1) / (steps * launches_per_step)
+        exchange_ms = sum(a.elapsed_time(b) for a, b in exchange_events) / steps if exchange_events else 0.0
+        # rays per step: deterministic scenes trace the same rays every frame; random modes vary by < 0.1 % between sample sets,
+        # so the count of the first timed step's sample set stands for every step (untimed pass: one stats read-back per render)
+        rays_rank = 0
+        for idx in sample_ids(warmup):
+            render(idx, acc=True if shard == "samples" else accumulate)
+            rays_rank += ctx.stats()["rays_total"]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    r = torch.tensor([float(rays_rank)], dtype=torch.float64, device="cuda")
-    if use_dist:
-        if xch.staged:
-            t, r = t.cpu(), r.cpu()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-    elapsed_max = float(t.item())
-    rays_per_step_all = float(r.item())
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        r = torch.tensor([float(rays_rank)], dtype=torch.float64, device="cuda")
+        if use_dist:
+            if xch.staged:
+                t, r = t.cpu(), r.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        elapsed_max = float(t.item())
+        rays_per_step_all = float(r.item())
 
-    if rank == 0:
-        # algorithmic FLOPs of one launch: event counts of a (slower, untimed) counting render times the per-event constants
-        render(1, acc=False, events=True)
-        st = ctx.stats()
-        flops = pkg.algorithmic_flops(st)
-        achieved = flops / (kernel_ms * 1e-3) / 1e12
-        value = rays_per_step_all * args.steps / elapsed_max / 1e6
-        traffic, traffic_note = measured_traffic(args.workload, pkg.LIB_PATH)
-        out = {
-            "metric": "Mrays/sec (primary+secondary) and frame ms at 4K",
-            "value": round(value, 2),
-            "unit": "Mrays/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak" if shard == "frames" else "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {description}", "width": width, "height": height,
-                       "max_ray_bounces": int(scene.desc.max_ray_bounces), "samples_per_step": spp,
-                       "rays_per_step_per_rank": int(rays_rank), "sharding": shard, "clock_prewarm_ms": int(CLOCK_PREWARM_S * 1e3),
-                       "accumulator_store": "n/a (accumulating)" if accumulate or shard == "samples" else ("skipped" if skip_store else "written"),
-                       "ranks": world, "backend": backend if use_dist else "none", "exchange_ms_per_step": round(exchange_ms, 4),
-                       "collective": ("none" if shard in ("none", "frames") or not xch.collectives else
-                                      "all_gather(rgba8 tile rows)" if shard == "rows" else
-                                      ("reduce_scatter(f32 accum) + all_gather(rgba8 bands)" if xch.reduce_scatter else "all_reduce(f32 accum) + all_gather(rgba8 bands)")),
-                       "parallelism": f"{shard}-sharded x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": traffic,
-                         # the 157.3 TFLOP/s peak is one FMA (2 flops) per lane every 2 cycles; bit-exact parity keeps multiplies
-                         # and adds unfused, so one flop per lane-instruction (half of it) bounds this code
-                         "frac_of_unfused_peak": round(achieved / (FP32_VALU_PEAK_TFLOPS / 2.0), 5),
-                         "kernel": kernel_name(pkg, scene),
-                         "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
-                         "note": "FP32 vector (VALU) roofline: this path has no dense contraction, so no MFMA"},
-        }
-        if traffic_note:
-            out["roofline"]["traffic_note"] = traffic_note
-        if traffic:
-            # the secondary bound: measured HBM bytes of one launch over the launch time, against the 8 TB/s HBM3E peak, and
-            # against the bytes the frame has to move at the least (4 B RGBA8 per pixel; 36 B when accumulating)
-            gbps = traffic / (kernel_ms * 1e-3) / 1e9
-            alg = width * height * (36 if (accumulate or shard == "samples") else 4)
-            out["roofline"]["hbm_view"] = {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
-                                           "algorithmic_bytes": alg, "traffic_over_algorithmic": round(traffic / alg, 2)}
-        if scene.desc.ray_marching:
-            # one sdfs() call evaluates the whole SDF list once (src/ray_marching/ray_marching.rs:24-107)
-            out["config"]["sdf_list_evals_per_s"] = round(st["sdfs_call"] / (kernel_ms * 1e-3), 1)
-        if world == 1 and not args.no_cpu_baseline:   # a reported baseline of the single-GPU line only
-            out["cpu_baseline"] = cpu_baseline(pkg, scene, width, height, accumulate)
+        out = None
+        if rank == 0:
+            # algorithmic FLOPs of one launch: event counts of a (slower, untimed) counting render times the per-event constants
+            render(1, acc=False, events=True)
+            st = ctx.stats()
+            flops = pkg.algorithmic_flops(st)
+            achieved = flops / (kernel_ms * 1e-3) / 1e12
+            value = rays_per_step_all * steps / elapsed_max / 1e6
+            traffic, traffic_note = measured_traffic(workload, pkg.LIB_PATH)
+            out = {
+                "metric": "Mrays/sec (primary+secondary) and frame ms at 4K",
+                "value": round(value, 2),
+                "unit": "Mrays/s",
+                "n_gpus": world,
+                "steps": steps,
+                "warmup": warmup,
+                "ms_per_step": round(elapsed_max / steps * 1e3, 4),
+                "higher_is_better": True,
+                "scaling": "weak" if shard == "frames" else "strong",
+                "vs_baseline": None,
+                "dtype": "f32",
+                "data": "synthetic",
+                "config": {"workload": f"{workload}: {description}", "width": width, "height": height,
+                           "max_ray_bounces": int(scene.desc.max_ray_bounces), "samples_per_step": spp,
+                           "rays_per_step_per_rank": int(rays_rank), "sharding": shard, "clock_prewarm_ms": int(CLOCK_PREWARM_S * 1e3),
+                           "accumulator_store": "n/a (accumulating)" if accumulate or shard == "samples" else ("skipped" if skip_store else "written"),
+                           "ranks": world, "backend": backend if use_dist else "none", "exchange_ms_per_step": round(exchange_ms, 4),
+                           "collective": ("none" if shard in ("none", "frames") or not xch.collectives else
+                                          "all_gather(rgba8 tile rows)" if shard == "rows" else
+                                          ("reduce_scatter(f32 accum) + all_gather(rgba8 bands)" if xch.reduce_scatter else "all_reduce(f32 accum) + all_gather(rgba8 bands)")),
+                           "parallelism": f"{shard}-sharded x{world}" if world > 1 else "single GPU"},
+                "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": traffic,
+                             # the 157.3 TFLOP/s peak is one FMA (2 flops) per lane every 2 cycles; bit-exact parity keeps multiplies
+                             # and adds unfused, so one flop per lane-instruction (half of it) bounds this code
+                             "frac_of_unfused_peak": round(achieved / (FP32_VALU_PEAK_TFLOPS / 2.0), 5),
+                             "kernel": kernel_name(pkg, scene),
+                             "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
+                             "note": "FP32 vector (VALU) roofline: this path has no dense contraction, so no MFMA"},
+            }
+            if traffic_note:
+                out["roofline"]["traffic_note"] = traffic_note
+            if traffic:
+                # the secondary bound: measured HBM bytes of one launch over the launch time, against the 8 TB/s HBM3E peak, and
+                # against the bytes the frame has to move at the least (4 B RGBA8 per pixel; 36 B when accumulating)
+                gbps = traffic / (kernel_ms * 1e-3) / 1e9
+                alg = width * height * (36 if (accumulate or shard == "samples") else 4)
+                out["roofline"]["hbm_view"] = {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                                               "algorithmic_bytes": alg, "traffic_over_algorithmic": round(traffic / alg, 2)}
+            if scene.desc.ray_marching:
+                # one sdfs() call evaluates the whole SDF list once (src/ray_marching/ray_marching.rs:24-107)
+                out["config"]["sdf_list_evals_per_s"] = round(st["sdfs_call"] / (kernel_ms * 1e-3), 1)
+            if world == 1 and want_cpu_baseline:   # a reported baseline of the single-GPU line only
+                out["cpu_baseline"] = cpu_baseline(pkg, scene, width, height, accumulate)
+        ctx.close()
+        del xch, rgba, accum
+        torch.cuda.empty_cache()
+        return out
+
+    out = measure(args.workload, args.steps, args.warmup, not args.no_cpu_baseline, args.shard)
+    if with_config5:
+        # BASELINE's multi-GPU configuration (8K, 10 000 spheres, 64 spp, sharded by sample index) rides along as a short
+        # second measurement, so that a run at N GPUs of the default workload also says how that frame scales
+        extra = measure("spheres10k_8k", 2, 1, False, None)
+        if out is not None and extra is not None:
+            out["config5"] = {"workload": extra["config"]["workload"], "value": extra["value"], "unit": extra["unit"], "n_gpus": extra["n_gpus"],
+                              "steps": extra["steps"], "warmup": extra["warmup"], "ms_per_step": extra["ms_per_step"], "scaling": extra["scaling"],
+                              "sharding": extra["config"]["sharding"], "collective": extra["config"]["collective"],
+                              "exchange_ms_per_step": extra["config"]["exchange_ms_per_step"],
+                              "kernel": extra["roofline"]["kernel"], "kernel_ms": extra["roofline"]["kernel_ms"], "frac": extra["roofline"]["frac"]}
+    if out is not None:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
-    ctx.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
