@@ -274,22 +274,43 @@ inline void rt_bvh2_build(const rt_scene_desc *d, RtBvh2 &out) {
     if (RtBvhBuilder::ceil_log2((uint32_t)ids.size()) + 1u > kBvh2MaxDepth) return;
     B.ids = ids;
     B.build(0, (uint32_t)B.ids.size());
-    // quantisation grid over the root box: q in [3, 65532] for coordinates inside it, so that the outward rounding below
-    // (floor - 1 / ceil + 1) stays inside 16 bits
+    // Coordinates are stored as binary16 numbers relative to the centre of the root box, +-32000 units at its faces.  The
+    // spacing of binary16 is 2^-11 of the distance from the centre (16 units at the faces, finer towards the centre); every
+    // plane first moves outward by one unit (2^-16 of the extent) and then to the next representable value outward.
     const RtAabb root = B.tree[0].box;
     double org[3], scl[3];
     for (int k = 0; k < 3; k++) {
         double ext = (double)root.hi[k] - (double)root.lo[k];
         if (!(ext > 0.0)) ext = 1e-6;
-        scl[k] = (double)(float)(ext / 65529.0 * 1.000001);
-        org[k] = (double)(float)((double)root.lo[k] - 3.0 * scl[k]);
+        scl[k] = (double)(float)(ext / 64000.0);
+        org[k] = (double)(float)(0.5 * ((double)root.lo[k] + (double)root.hi[k]));
         out.scale[k] = (float)scl[k]; out.origin[k] = (float)org[k];
     }
+    // binary16 with directed rounding: the nearest representable value at or beyond x in the given direction
+    auto half_dir = [](double x, bool up) -> uint16_t {
+        const bool neg = x < 0.0;
+        const double a = neg ? -x : x;
+        const bool mag_up = (up != neg);
+        if (a == 0.0) return 0;
+        uint32_t bits;
+        if (a < 6.103515625e-05) {                       // below 2^-14: subnormal spacing 2^-24
+            const double n = a * 16777216.0;
+            bits = (uint32_t)(mag_up ? std::ceil(n) : std::floor(n));   // 1024 rolls over into the first normal number
+        } else {
+            int e; const double m = std::frexp(a, &e);   // a = m * 2^e, m in [0.5, 1)
+            const double f = (m * 2.0 - 1.0) * 1024.0;
+            uint32_t mant = (uint32_t)(mag_up ? std::ceil(f) : std::floor(f));
+            uint32_t ex = (uint32_t)(e - 1 + 15);
+            if (mant == 1024u) { mant = 0u; ex += 1u; }
+            if (ex >= 31u) { ex = 30u; mant = 1023u; }   // 65504: never reached by coordinates within +-32032
+            bits = (ex << 10) | mant;
+        }
+        return (uint16_t)((neg ? 0x8000u : 0u) | bits);
+    };
     auto quant = [&](const RtAabb &b, uint16_t q[6]) {
         for (int k = 0; k < 3; k++) {
-            double lo = std::floor(((double)b.lo[k] - org[k]) / scl[k]) - 1.0, hi = std::ceil(((double)b.hi[k] - org[k]) / scl[k]) + 1.0;
-            lo = std::min(std::max(lo, 0.0), 65535.0); hi = std::min(std::max(hi, 0.0), 65535.0);
-            q[2 * k] = (uint16_t)lo; q[2 * k + 1] = (uint16_t)hi;   // one dword per axis: lower | upper << 16
+            const double lo = ((double)b.lo[k] - org[k]) / scl[k] - 1.0, hi = ((double)b.hi[k] - org[k]) / scl[k] + 1.0;
+            q[2 * k] = half_dir(lo, false); q[2 * k + 1] = half_dir(hi, true);   // one dword per axis: lower | upper << 16
         }
     };
     // inner nodes in depth-first order

@@ -68,8 +68,10 @@ struct DevBvhNode {
 };
 
 // Two-child node of the quantised hierarchy (rt_bvh.h, rt_bvh2_build): q[0..5] = the first child's box as (lower, upper)
-// pairs for x, y, z (one dword per axis), q[6..11] the second child's, on the 16-bit grid of DevScene.bvh2_origin / bvh2_scale; ref >= 0: byte
-// offset of an inner node in the node array, ref < 0: ~((object kind << 28) | object index).
+// pairs for x, y, z (one dword per axis), q[6..11] the second child's.  Each q is a binary16 bit pattern: the coordinate
+// is DevScene.bvh2_origin + q * bvh2_scale (origin = centre of the root box, +-32000 units at its faces), rounded outward,
+// so that one mixed-precision FMA per plane decodes and intersects it.  ref >= 0: byte offset of an inner node in the node
+// array, ref < 0: ~((object kind << 28) | object index).
 struct DevBvh2Node {
     uint16_t q[12];
     int32_t ref[2];

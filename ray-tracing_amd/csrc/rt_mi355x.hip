@@ -578,13 +578,13 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
             c->wf_groups = (uint32_t)per_cu * (uint32_t)cus;
         }
         W.tiles_x = (c->camera.width + kWfTileW - 1u) / kWfTileW; W.tiles_y = tiles_y;
-        grid = dim3(std::min<uint32_t>(c->wf_groups, W.tiles_x * W.tiles_y));
+        grid = dim3(std::min<uint32_t>(c->wf_groups, W.tiles_x * W.tiles_y * 8u));   // at most eight items per tile
         blocks = grid.x;
         RT_HIP(c, c->wf_pool.ensure((size_t)c->wf_groups * kWfPool * 4u));   // four float4 planes per pool entry
-        RT_HIP(c, c->wf_ctrl.ensure(2u + (size_t)tiles_y));
+        RT_HIP(c, c->wf_ctrl.ensure((size_t)kWfCtrlRows + tiles_y));
         {   // the per-row costs only describe a launch over the same rows of the same frame
             const uint64_t key = ((uint64_t)c->camera.width << 40) ^ ((uint64_t)c->camera.height << 20) ^ ((uint64_t)rb << 44) ^ ((uint64_t)re << 8) ^ stride ^ ((uint64_t)c->scene_serial << 52);
-            if (key != c->wf_order_key) { RT_HIP(c, hipMemsetAsync(c->wf_ctrl.ptr, 0, (2u + (size_t)tiles_y) * sizeof(uint32_t), s)); c->wf_order_key = key; }
+            if (key != c->wf_order_key) { RT_HIP(c, hipMemsetAsync(c->wf_ctrl.ptr, 0, ((size_t)kWfCtrlRows + tiles_y) * sizeof(uint32_t), s)); c->wf_order_key = key; }
         }
         const size_t plane = (size_t)c->wf_groups * kWfPool;
         W.a = c->wf_pool.ptr; W.b = W.a + plane; W.c = W.b + plane; W.d = W.c + plane;
@@ -621,7 +621,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
     const bool time_kernel = p->no_timing == 0;
     if (time_kernel) RT_HIP(c, hipEventRecord(c->ev0, s));
     if (regroup) {
-        hipLaunchKernelGGL(rt_wf_order_kernel, dim3(1), dim3(256), 0, s, W.ctrl, W.tiles_y);
+        hipLaunchKernelGGL(rt_wf_order_kernel, dim3(1), dim3(256), 0, s, W.ctrl, W.tiles_x, W.tiles_y, grid.x);
 #ifdef RT_WF_STATS
         static unsigned long long *s_wfstats = nullptr;
         if (!s_wfstats) (void)hipMalloc((void **)&s_wfstats, 2 * WS_N * sizeof(unsigned long long));
@@ -635,6 +635,23 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(h, s_wfstats, sizeof(h), hipMemcpyDeviceToHost);
             static const char *names[WS_N] = {"refill", "walk step", "leaf test", "finish", "shade batch", "prepare batch"};
+            {   // start / end of every wavefront: how much of the launch is a tail of few busy wavefronts
+                std::vector<float4> all((size_t)grid.x * kWfPool);
+                (void)hipMemcpy(all.data(), W.a, all.size() * sizeof(float4), hipMemcpyDeviceToHost);
+                std::vector<double> t0(grid.x), t1(grid.x);
+                auto u = [](float lo, float hi) { uint32_t a, b; std::memcpy(&a, &lo, 4); std::memcpy(&b, &hi, 4); return (double)(((unsigned long long)b << 32) | a); };
+                double first = 1e300, last = 0.0, busy = 0.0;
+                for (uint32_t g = 0; g < grid.x; g++) { const float4 v = all[(size_t)g * kWfPool]; t0[g] = u(v.x, v.y); t1[g] = u(v.z, v.w); first = std::min(first, t0[g]); last = std::max(last, t1[g]); busy += t1[g] - t0[g]; }
+                const double span = last - first;
+                std::vector<double> ends(t1); std::sort(ends.begin(), ends.end());
+                fprintf(stderr, "WFSTAT span %.1f us, mean wavefront busy %.1f %% of it; wavefronts still running at 70/80/90/95 %% of the span: ", span / 100.0, 100.0 * busy / (span * grid.x));
+                for (double f : {0.7, 0.8, 0.9, 0.95}) { const double t = first + f * span; fprintf(stderr, "%ld ", (long)(ends.end() - std::lower_bound(ends.begin(), ends.end(), t))); }
+                fprintf(stderr, "of %u\n", grid.x);
+                std::vector<double> starts(t0); std::sort(starts.begin(), starts.end());
+                fprintf(stderr, "WFSTAT starts after the first one (us): median %.1f, 90 %% %.1f, 99 %% %.1f, last %.1f; ends before the last one (us): median %.1f, 10 %% %.1f, 1 %% %.1f\n",
+                        (starts[grid.x / 2] - first) / 100.0, (starts[(size_t)(grid.x * 0.9)] - first) / 100.0, (starts[(size_t)(grid.x * 0.99)] - first) / 100.0, (starts.back() - first) / 100.0,
+                        (last - ends[grid.x / 2]) / 100.0, (last - ends[(size_t)(grid.x * 0.1)]) / 100.0, (last - ends[(size_t)(grid.x * 0.01)]) / 100.0);
+            }
             for (int i = 0; i < WS_N; i++) fprintf(stderr, "WFSTAT %-14s runs %12llu lanes %14llu  mean lanes %5.1f\n", names[i], h[2 * i], h[2 * i + 1], h[2 * i] ? (double)h[2 * i + 1] / (double)h[2 * i] : 0.0);
         }
 #endif

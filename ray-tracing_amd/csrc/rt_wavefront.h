@@ -55,12 +55,21 @@ enum { WS_REFILL = 0, WS_WALK, WS_LEAF, WS_FINISH, WS_SHADE, WS_PREPARE, WS_N };
 #define WS_PASS
 #endif
 
+// Layout of WfArgs::ctrl.  Work is handed out as items from one counter.  Along the launch order of the tile rows the items
+// shrink: rows [0, R1) are dealt as whole tiles (512 paths), [R1, R2) as halves (256), [R2, R3) as quarters (128), the rest as
+// eighths (64), so that the launch does not end on a few wavefronts that started a large, expensive tile late.
+// ITEMS_c = first item index of size class c + 1 (ITEMS_3 = number of items), TILE_c = first whole tile of class c.
+enum { kWfCtrlNext = 0, kWfCtrlRowOffset = 1, kWfCtrlItems0 = 2, kWfCtrlItems1 = 3, kWfCtrlItems2 = 4, kWfCtrlItems3 = 5,
+       kWfCtrlTile2 = 6, kWfCtrlTile3 = 7, kWfCtrlRows = 16 };
+
+constexpr float kWfSlack = 4.76837158e-7f;   // 2^-21: bound on the relative rounding error of a decoded plane distance
+
 struct WfArgs {
     float4 *a;   // per pool entry: ray origin xyz, RNG key
     float4 *b;   //                 ray direction xyz, pixel index
     float4 *c;   //                 carried light xyz, contribution x
     float4 *d;   //                 contribution y, z; closest hit so far: distance, object | sub << 30 (kWfHitMiss: none)
-    uint32_t *ctrl;   // [0] next tile to hand out, [1] first tile row of this launch's order, [2 + r] rays traced in tile row r
+    uint32_t *ctrl;   // kWfCtrl* header words, then [kWfCtrlRows + r] = rays traced in tile row r
     uint32_t tiles_x, tiles_y;
     unsigned long long *stats;   // diagnostic builds only
 };
@@ -103,7 +112,7 @@ RT_DEV void wf_trace_pool(const DevScene &S, const DevCamera &C, const DevFrame 
     int cur = -1;         // inner node to visit next, -1: none left
     int pend0 = 0, pend1 = 0;   // leaves waiting for their candidate test (negative references), 0: none
     uint32_t sp = 0u;
-    f3 ro = splat3(0.0f), rd = splat3(0.0f), ka = splat3(0.0f), kb = splat3(0.0f);
+    f3 ro = splat3(0.0f), rd = splat3(0.0f), ka = splat3(0.0f), kn = splat3(0.0f), kf = splat3(0.0f);
     struct { uint32_t x, y, z; } rot = {0u, 0u, 0u};   // 16 where the direction component is negative
     int best = -1, best_sub = 0;
     float closest = RT_F32_MAX;
@@ -134,11 +143,23 @@ RT_DEV void wf_trace_pool(const DevScene &S, const DevCamera &C, const DevFrame 
                         const uint32_t hb = __float_as_uint(h0.y);
                         best = hb == kWfHitMiss ? -1 : (int)(hb & 0x0FFFFFFFu); best_sub = hb == kWfHitMiss ? 0 : (int)(hb >> 30);
                         pend0 = 0; pend1 = 0; sp = 0u; cur = 0;
-                        // box test on the 16-bit grid: t = (origin + q * scale - ro) / rd = q * ka + kb
-                        // (the box test only steers the traversal: an approximate reciprocal is as good as the exact quotient)
-                        const f3 inv = mk3(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));
+                        // box test on the quantised planes: t = (origin + q * scale - ro) / rd = q * ka + kb
+                        // (the box test only steers the traversal: an approximate reciprocal is as good as the exact quotient).
+                        // The rounding of ka, kb and the FMA is at most 2^-21 of |kb| + 32768 |ka| in t; entry planes are taken
+                        // that much earlier (kn) and exit planes that much later (kf), so no box is missed however far the ray
+                        // starts from the scene.
+                        // A zero direction component would give 0 * inf = NaN planes, which never cull: such a ray (the camera rays
+                        // of the frame's centre column, for one) would walk every node its other two slabs let through.  For the
+                        // box test the component is at least 1e-20 in magnitude: the planes it meets lie at +-huge, finite t.
+                        const f3 inv = mk3(__builtin_amdgcn_rcpf(__builtin_copysignf(rt_max(rt_abs(rd.x), 1e-20f), rd.x)),
+                                           __builtin_amdgcn_rcpf(__builtin_copysignf(rt_max(rt_abs(rd.y), 1e-20f), rd.y)),
+                                           __builtin_amdgcn_rcpf(__builtin_copysignf(rt_max(rt_abs(rd.z), 1e-20f), rd.z)));
                         ka = gscl * inv;
-                        kb = (gorg - ro) * inv;
+                        const f3 kb = (gorg - ro) * inv;
+                        const f3 slack = mk3(kWfSlack * (rt_abs(kb.x) + 32768.0f * rt_abs(ka.x)), kWfSlack * (rt_abs(kb.y) + 32768.0f * rt_abs(ka.y)),
+                                             kWfSlack * (rt_abs(kb.z) + 32768.0f * rt_abs(ka.z)));
+                        kn = kb - slack;
+                        kf = kb + slack;
                         rot.x = (__float_as_uint(rd.x) >> 31) << 4; rot.y = (__float_as_uint(rd.y) >> 31) << 4; rot.z = (__float_as_uint(rd.z) >> 31) << 4;
                     }
                 }
@@ -166,11 +187,15 @@ RT_DEV void wf_trace_pool(const DevScene &S, const DevCamera &C, const DevFrame 
                 // plane the ray meets first into the low half, so no per-axis min / max is needed
                 const uint32_t lx = __builtin_amdgcn_alignbit(n0.x, n0.x, rot.x), ly = __builtin_amdgcn_alignbit(n0.y, n0.y, rot.y), lz = __builtin_amdgcn_alignbit(n0.z, n0.z, rot.z);
                 const uint32_t rx = __builtin_amdgcn_alignbit(n0.w, n0.w, rot.x), ry = __builtin_amdgcn_alignbit(n1.x, n1.x, rot.y), rz = __builtin_amdgcn_alignbit(n1.y, n1.y, rot.z);
+                typedef _Float16 wf_h2 __attribute__((ext_vector_type(2)));
+                const wf_h2 hlx = __builtin_bit_cast(wf_h2, lx), hly = __builtin_bit_cast(wf_h2, ly), hlz = __builtin_bit_cast(wf_h2, lz);
+                const wf_h2 hrx = __builtin_bit_cast(wf_h2, rx), hry = __builtin_bit_cast(wf_h2, ry), hrz = __builtin_bit_cast(wf_h2, rz);
+                // one v_fma_mix_f32 per plane (binary16 coordinate, binary32 ka / kb);
                 // a NaN (0 * inf, inf - inf for rays parallel to an axis) is dropped by max3 / min3: such a slab does not cull
-                const float ltmin = rt_max3(__builtin_fmaf((float)(lx & 0xFFFFu), ka.x, kb.x), __builtin_fmaf((float)(ly & 0xFFFFu), ka.y, kb.y), rt_max(__builtin_fmaf((float)(lz & 0xFFFFu), ka.z, kb.z), 0.0f));
-                const float ltmax = rt_min3(__builtin_fmaf((float)(lx >> 16), ka.x, kb.x), __builtin_fmaf((float)(ly >> 16), ka.y, kb.y), __builtin_fmaf((float)(lz >> 16), ka.z, kb.z));
-                const float rtmin = rt_max3(__builtin_fmaf((float)(rx & 0xFFFFu), ka.x, kb.x), __builtin_fmaf((float)(ry & 0xFFFFu), ka.y, kb.y), rt_max(__builtin_fmaf((float)(rz & 0xFFFFu), ka.z, kb.z), 0.0f));
-                const float rtmax = rt_min3(__builtin_fmaf((float)(rx >> 16), ka.x, kb.x), __builtin_fmaf((float)(ry >> 16), ka.y, kb.y), __builtin_fmaf((float)(rz >> 16), ka.z, kb.z));
+                const float ltmin = rt_max3(__builtin_fmaf((float)hlx.x, ka.x, kn.x), __builtin_fmaf((float)hly.x, ka.y, kn.y), rt_max(__builtin_fmaf((float)hlz.x, ka.z, kn.z), 0.0f));
+                const float ltmax = rt_min3(__builtin_fmaf((float)hlx.y, ka.x, kf.x), __builtin_fmaf((float)hly.y, ka.y, kf.y), __builtin_fmaf((float)hlz.y, ka.z, kf.z));
+                const float rtmin = rt_max3(__builtin_fmaf((float)hrx.x, ka.x, kn.x), __builtin_fmaf((float)hry.x, ka.y, kn.y), rt_max(__builtin_fmaf((float)hrz.x, ka.z, kn.z), 0.0f));
+                const float rtmax = rt_min3(__builtin_fmaf((float)hrx.y, ka.x, kf.x), __builtin_fmaf((float)hry.y, ka.y, kf.y), __builtin_fmaf((float)hrz.y, ka.z, kf.z));
                 const bool lhit = ltmin <= ltmax && ltmin <= closest, rhit = rtmin <= rtmax && rtmin <= closest;
                 const int lref = (int)n1.z, rref = (int)n1.w;
                 // leaves whose box is hit wait for their candidate test; inner children are visited near one first
@@ -223,30 +248,39 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_diffuse_kernel(const De
     float4 *pa = W.a + (size_t)blockIdx.x * kWfPool, *pb = W.b + (size_t)blockIdx.x * kWfPool, *pc = W.c + (size_t)blockIdx.x * kWfPool;
     float4 *pd = W.d + (size_t)blockIdx.x * kWfPool;
     const uint32_t maxd = S.max_ray_bounces;
-    const uint32_t n_tiles = W.tiles_x * W.tiles_y;
     const f3 ambient = ld3(S.ambient);
     const bool jitter = S.enable_accumulation != 0u;
     uint32_t rays = 0u;
     Cnt<false> nocnt;
-    const uint32_t row_offset = W.ctrl[1];
+    const uint32_t row_offset = W.ctrl[kWfCtrlRowOffset];
+    const uint32_t items0 = W.ctrl[kWfCtrlItems0], items1 = W.ctrl[kWfCtrlItems1], items2 = W.ctrl[kWfCtrlItems2], items3 = W.ctrl[kWfCtrlItems3];
+    const uint32_t tile2 = W.ctrl[kWfCtrlTile2], tile3 = W.ctrl[kWfCtrlTile3];
 #ifdef RT_WF_STATS
+    const unsigned long long ws_t0 = wall_clock64();
     __shared__ uint32_t s_stat[2 * WS_N];
     if (lane < 2u * WS_N) s_stat[lane] = 0u;
     __syncthreads();
 #endif
     for (;;) {
-        uint32_t tile = 0u;
-        if (lane == 0u) tile = atomicAdd(&W.ctrl[0], 1u);
-        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-        if (tile >= n_tiles) break;
+        uint32_t item = 0u;
+        if (lane == 0u) item = atomicAdd(&W.ctrl[kWfCtrlNext], 1u);
+        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+        if (item >= items3) break;
+        // item -> (tile, part of the tile, size class): wave-uniform
+        uint32_t cls, tile, part;
+        if (item < items0) { cls = 0u; tile = item; part = 0u; }
+        else if (item < items1) { const uint32_t q = item - items0; cls = 1u; tile = items0 + (q >> 1); part = q & 1u; }
+        else if (item < items2) { const uint32_t q = item - items1; cls = 2u; tile = tile2 + (q >> 2); part = q & 3u; }
+        else { const uint32_t q = item - items2; cls = 3u; tile = tile3 + (q >> 3); part = q & 7u; }
+        const uint32_t n_slots = kWfPool >> cls;   // paths of this item: n_slots / 64 blocks of 8x8 pixels side by side
         const uint32_t trow = tile / W.tiles_x, tx = tile - trow * W.tiles_x;
                 // tile rows top-down, starting at the row the order kernel chose from the previous launch's costs and wrapping around
         uint32_t rrow = trow + row_offset;
         if (rrow >= W.tiles_y) rrow -= W.tiles_y;
-        const uint32_t x0 = tx * kWfTileW, y0 = F.row_begin + rrow * F.tile_row_step;
+        const uint32_t x0 = tx * kWfTileW + part * (kWfTileW >> cls), y0 = F.row_begin + rrow * F.tile_row_step;
         const uint32_t rays_before = rays;
         // ---- camera rays against the linear objects, all lanes busy
-        for (uint32_t base = 0u; base < kWfPool; base += 64u) {
+        for (uint32_t base = 0u; base < n_slots; base += 64u) {
             const uint32_t j = base + lane;
             uint32_t pos;
             float closest = RT_F32_MAX;
@@ -257,7 +291,7 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_diffuse_kernel(const De
             pd[j] = make_float4(1.0f, 1.0f, closest, __uint_as_float(best == (int)kWfHitInvalid ? kWfHitInvalid : wf_pack_hit(best, best_sub)));
         }
         __syncthreads();
-        uint32_t n = kWfPool;
+        uint32_t n = n_slots;
         for (uint32_t depth = 0u; depth < maxd && n > 0u; depth++) {
             const bool primary = depth == 0u;
             wf_trace_pool(S, C, F, primary, n, x0, y0, pa, pb, pd, s_stack, rays WS_PASS);
@@ -330,7 +364,7 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_diffuse_kernel(const De
             uint32_t tr = rays - rays_before;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) tr += __shfl_xor(tr, off, 64);
-            if (lane == 0u) atomicAdd(&W.ctrl[2u + rrow], tr);
+            if (lane == 0u) atomicAdd(&W.ctrl[kWfCtrlRows + rrow], tr);
         }
     }
 #pragma unroll
@@ -339,6 +373,10 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_diffuse_kernel(const De
 #ifdef RT_WF_STATS
     __syncthreads();
     if (lane < 2u * WS_N && W.stats) atomicAdd(&W.stats[lane], (unsigned long long)s_stat[lane]);
+    if (lane == 0u) {   // when this wavefront started and ended (100 MHz counter), left in its first pool slot for the host
+        const unsigned long long t1 = wall_clock64();
+        pa[0] = make_float4(__uint_as_float((uint32_t)ws_t0), __uint_as_float((uint32_t)(ws_t0 >> 32)), __uint_as_float((uint32_t)t1), __uint_as_float((uint32_t)(t1 >> 32)));
+    }
 #endif
 }
 
@@ -348,33 +386,73 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_diffuse_kernel(const De
 // scattering rows loses the cache locality of neighbouring tiles.  So rows stay in top-down order, rotated so that the
 // cheapest three eighths of the frame (by the rays the previous launch traced per row; a contiguous block, wrapping) come
 // last.  Without history (first launch, or a new camera / row range) the order is plain top-down.  Pixels do not depend on it.
+//
+// The same pass sizes the items (see kWfCtrl*).  An item finishes before the launch does if its work is at most the work
+// still to be handed out divided by the number of wavefronts; going down the launch order, the item size of a row is the
+// largest one for which that holds (by the previous launch's rays per row; uniform rows without history), and it never grows
+// again.  How small items may get depends on how many whole tiles there are per wavefront (see max_cls below).
 constexpr uint32_t kWfMaxOrderRows = 8192u;
-__global__ void __launch_bounds__(256) rt_wf_order_kernel(uint32_t *ctrl, uint32_t tiles_y) {
+#ifndef RT_WF_GUIDE
+#define RT_WF_GUIDE 1.0f     // safety factor on an item's work in that comparison
+#endif
+__global__ void __launch_bounds__(256) rt_wf_order_kernel(uint32_t *ctrl, uint32_t tiles_x, uint32_t tiles_y, uint32_t groups) {
     __shared__ uint32_t s_pre[kWfMaxOrderRows + 1u];
     __shared__ unsigned long long s_best;
+    __shared__ uint32_t s_offset;
     const uint32_t T = tiles_y, L = (T * 3u) / 8u;
-    uint32_t offset = 0u;
-    if (T <= kWfMaxOrderRows && L > 0u) {
+    const bool history = T <= kWfMaxOrderRows;
+    if (threadIdx.x == 0u) s_offset = 0u;
+    if (history) {
         if (threadIdx.x == 0u) {
             uint32_t acc = 0u;
             s_pre[0] = 0u;
-            for (uint32_t r = 0; r < T; r++) { acc += ctrl[2u + r]; s_pre[r + 1u] = acc; }
+            for (uint32_t r = 0; r < T; r++) { acc += ctrl[kWfCtrlRows + r]; s_pre[r + 1u] = acc; }
             s_best = ~0ull;
         }
         __syncthreads();
         const uint32_t total = s_pre[T];
-        if (total != 0u) {
+        if (total != 0u && L > 0u) {
             for (uint32_t s0 = threadIdx.x; s0 < T; s0 += blockDim.x) {   // window [s0, s0 + L), wrapping
                 const uint32_t e = s0 + L;
                 const uint32_t sum = e <= T ? s_pre[e] - s_pre[s0] : (total - s_pre[s0]) + s_pre[e - T];
                 atomicMin(&s_best, ((unsigned long long)sum << 32) | s0);
             }
             __syncthreads();
-            const uint32_t s0 = (uint32_t)(s_best & 0xFFFFFFFFull);
-            offset = (s0 + L) % T;
+            if (threadIdx.x == 0u) s_offset = ((uint32_t)(s_best & 0xFFFFFFFFull) + L) % T;
         }
     }
     __syncthreads();
-    for (uint32_t r = threadIdx.x; r < T; r += blockDim.x) ctrl[2u + r] = 0u;
-    if (threadIdx.x == 0u) { ctrl[0] = 0u; ctrl[1] = offset; }
+    if (threadIdx.x == 0u) {
+        const uint32_t offset = s_offset;
+        const bool costs = history && s_pre[T] != 0u;
+        // work of launch-order row k and of the rows from k on
+        auto row_work = [&](uint32_t k) -> float {
+            if (!costs) return 1.0f;
+            uint32_t r = k + offset; if (r >= T) r -= T;
+            const uint32_t w = s_pre[r + 1u] - s_pre[r];
+            return (float)(w > 0u ? w : 1u);
+        };
+        float remaining = 0.0f;
+        for (uint32_t k = 0; k < T; k++) remaining += row_work(k);
+        // smallest item size allowed: halves below four whole tiles per wavefront, quarters below one, eighths below a quarter
+        // (measured on the 10 000-sphere frame: at 4K, 2.3 tiles per wavefront, halves gain 10 % and quarters 5 %; at 8K, 9 tiles
+        // per wavefront, every smaller size loses 1-3 %: short pools drain at low occupancy)
+        const uint32_t n_tiles = tiles_x * T;
+        const uint32_t max_cls = n_tiles >= 4u * groups ? 0u : (n_tiles >= groups ? 1u : (4u * n_tiles >= groups ? 2u : 3u));
+        uint32_t first_row[4] = {0u, T, T, T};   // first launch-order row of each size class
+        uint32_t cls = 0u;
+        for (uint32_t k = 0; k < T; k++) {
+            const float w = row_work(k);
+            const float item = RT_WF_GUIDE * (float)groups * w / (float)tiles_x;   // groups x (work of one whole tile of this row)
+            while (cls < max_cls && item > remaining * (float)(1u << cls)) { cls++; first_row[cls] = k; }
+            remaining -= w;
+        }
+        const uint32_t r1 = first_row[1], r2 = first_row[2], r3 = first_row[3];
+        const uint32_t i0 = r1 * tiles_x, i1 = i0 + (r2 - r1) * tiles_x * 2u, i2 = i1 + (r3 - r2) * tiles_x * 4u, i3 = i2 + (T - r3) * tiles_x * 8u;
+        ctrl[kWfCtrlNext] = 0u; ctrl[kWfCtrlRowOffset] = offset;
+        ctrl[kWfCtrlItems0] = i0; ctrl[kWfCtrlItems1] = i1; ctrl[kWfCtrlItems2] = i2; ctrl[kWfCtrlItems3] = i3;
+        ctrl[kWfCtrlTile2] = r2 * tiles_x; ctrl[kWfCtrlTile3] = r3 * tiles_x;
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < T; r += blockDim.x) ctrl[kWfCtrlRows + r] = 0u;
 }
