@@ -215,14 +215,14 @@ inline void rt_bvh_build(const rt_scene_desc *d, std::vector<DevBvhNode> &nodes,
 // ------------------------------------------------------------------------------------------------
 // Second form of the hierarchy, for the kernel that re-groups rays (rt_wavefront.h): only inner nodes, each holding the
 // boxes of BOTH children, so one visit decides about two subtrees and a ray needs half as many dependent fetches.  The
-// boxes are quantised to 16 bits per coordinate on a grid over the root box: a node is 32 bytes (two 16-byte loads)
+// boxes are quantised to 16 bits (binary16) per coordinate relative to the centre of the root box: a node is 32 bytes (two 16-byte loads)
 // instead of 64, and the whole tree of 10 000 objects is 320 KB.  Traversal uses a small per-lane stack (near child first),
 // so the tree is depth-limited (kBvh2MaxDepth) and needs no per-octant copies.
 // Objects so large that they would stretch the grid (a ground sphere of radius 1000 under spheres of radius 0.5) are left
 // out of this tree and tested linearly, like the planes.
 // ------------------------------------------------------------------------------------------------
 #ifndef RT_WF_STACK
-#define RT_WF_STACK 22
+#define RT_WF_STACK 20
 #endif
 constexpr uint32_t kBvh2MaxDepth = RT_WF_STACK;     // inner levels; the kernel's traversal stack has this many entries
 constexpr uint32_t kBvh2MaxOutliers = 8;

@@ -648,6 +648,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
                 for (double f : {0.7, 0.8, 0.9, 0.95}) { const double t = first + f * span; fprintf(stderr, "%ld ", (long)(ends.end() - std::lower_bound(ends.begin(), ends.end(), t))); }
                 fprintf(stderr, "of %u\n", grid.x);
                 std::vector<double> starts(t0); std::sort(starts.begin(), starts.end());
+                fprintf(stderr, "WFSTAT wavefronts started within 20 us of the first: %ld of %u\n", (long)(std::upper_bound(starts.begin(), starts.end(), first + 2000.0) - starts.begin()), grid.x);
                 fprintf(stderr, "WFSTAT starts after the first one (us): median %.1f, 90 %% %.1f, 99 %% %.1f, last %.1f; ends before the last one (us): median %.1f, 10 %% %.1f, 1 %% %.1f\n",
                         (starts[grid.x / 2] - first) / 100.0, (starts[(size_t)(grid.x * 0.9)] - first) / 100.0, (starts[(size_t)(grid.x * 0.99)] - first) / 100.0, (starts.back() - first) / 100.0,
                         (last - ends[grid.x / 2]) / 100.0, (last - ends[(size_t)(grid.x * 0.1)]) / 100.0, (last - ends[(size_t)(grid.x * 0.01)]) / 100.0);

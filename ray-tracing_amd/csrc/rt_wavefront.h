@@ -30,17 +30,20 @@
 #endif
 constexpr uint32_t kWfPool = RT_WF_POOL;              // paths per wavefront pool = pixels per tile
 constexpr uint32_t kWfTileW = kWfPool / 8u, kWfTileH = 8u;   // tile = sub-tiles of 8x8 pixels side by side
+// Traversal stack entries per lane (>= kBvh2MaxDepth of rt_bvh.h).  LDS is granted in blocks of 1280 bytes: 20 entries x 64
+// lanes x 4 bytes are exactly four blocks, 32 wavefronts per CU; 21 or 22 entries take a fifth block and leave room for 25
+// (measured: 22 entries 325.1 ms per 8K frame, 20 entries 320.0, and 317.7 compiled for 8 wavefronts per SIMD).
 #ifndef RT_WF_STACK
-#define RT_WF_STACK 22
+#define RT_WF_STACK 20
 #endif
-constexpr uint32_t kWfStack = RT_WF_STACK;            // traversal stack entries per lane (>= kBvh2MaxDepth of rt_bvh.h)
+constexpr uint32_t kWfStack = RT_WF_STACK;
 constexpr uint32_t kWfHitMiss = 0xFFFFFFFFu, kWfHitInvalid = 0xFFFFFFFEu;
 
 #ifndef RT_WF_REFILL
 #define RT_WF_REFILL 16      // idle lanes that trigger a refill from the pool
 #endif
 #ifndef RT_WF_WAVES
-#define RT_WF_WAVES 7        // wavefronts per SIMD the kernel is compiled for
+#define RT_WF_WAVES 8        // wavefronts per SIMD the kernel is compiled for (64 registers, no spills)
 #endif
 
 // Diagnostic build (-DRT_WF_STATS): per phase, how often it ran and with how many lanes (never enabled in the shipped library).
