@@ -85,6 +85,8 @@ def main() -> None:
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: scene3_4k (BASELINE configs[1]), followed by a short config-5 measurement")
     ap.add_argument("--shard", default=None, choices=["frames", "rows", "samples"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--consecutive-launches", action="store_true",
+                    help="multi-sample workloads: one rt_render_device call per sample instead of one rt_render_samples_device call per frame (profiling runs)")
     ap.add_argument("--no-config5", action="store_true",
                     help="default workload only: without the ride-along measurement of the 8K / 10 000-sphere / 64-spp frame")
     ap.add_argument("--keep-accum-store", action="store_true",
@@ -184,6 +186,8 @@ def main() -> None:
             return [1 + i * spp + k for k in range(spp)]
 
         kernel_events, exchange_events = [], []
+        # multi-sample frames go through rt_render_samples_device (one call per frame and rank; sample_ids are contiguous)
+        batched = spp > 1 and not args.consecutive_launches and (shard == "samples" or accumulate) and shard != "frames"
 
         def step(i: int, timed: bool = False) -> None:
             # per-step events only where a step has collectives to separate from the render launches (an event pair costs
@@ -194,8 +198,14 @@ def main() -> None:
                 k0.record(stream)
             if shard == "samples":
                 accum.zero_()
-            for idx in sample_ids(i):
-                render(idx, acc=True if shard == "samples" else accumulate)
+            ids = sample_ids(i)
+            if batched and len(ids) > 1:
+                # the samples of a frame in one call: the library overlaps launches of interleaved shares of the rows
+                ctx.render_samples_device(ids[0], len(ids), seed=0x5EED, rows=(rows_arg[0], rows_arg[1]) if rows_arg else None,
+                                          tile_row_stride=rows_arg[2] if rows_arg else 0, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh)
+            else:
+                for idx in ids:
+                    render(idx, acc=True if shard == "samples" else accumulate)
             if timed:
                 k1.record(stream)
                 kernel_events.append((k0, k1))
@@ -245,7 +255,19 @@ def main() -> None:
         launches_per_step = len(sample_ids(0))
         # average launch duration of the render kernel(s), from events on the launch stream: around each step's render launches
         # when the step also has collectives, around the whole timed loop (launches back to back) otherwise
-        if kernel_events:
+        if batched:
+            # the batch call overlaps launches of row shares, so the timed region does not show the duration of a launch: a few
+            # whole-frame launches, one after the other, are timed for the roofline line after the timed region
+            probe = min(8, launches_per_step)
+            p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            render(1, acc=True)
+            p0.record(stream)
+            for k in range(probe):
+                render(2 + k, acc=True)
+            p1.record(stream)
+            torch.cuda.synchronize()
+            kernel_ms = p0.elapsed_time(p1) / probe
+        elif kernel_events:
             kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / (steps * launches_per_step)
         else:
             kernel_ms = ev0.elapsed_time(ev1) / (steps * launches_per_step)
@@ -297,7 +319,9 @@ def main() -> None:
                            "collective": ("none" if shard in ("none", "frames") or not xch.collectives else
                                           "all_gather(rgba8 tile rows)" if shard == "rows" else
                                           ("reduce_scatter(f32 accum) + all_gather(rgba8 bands)" if xch.reduce_scatter else "all_reduce(f32 accum) + all_gather(rgba8 bands)")),
-                           "parallelism": f"{shard}-sharded x{world}" if world > 1 else "single GPU"},
+                           "parallelism": f"{shard}-sharded x{world}" if world > 1 else "single GPU",
+                       "samples_call": ("rt_render_samples_device (one call per frame: launches of four interleaved row shares overlap; "
+                                        "roofline.kernel_ms is a whole-frame launch timed alone)") if batched else "rt_render_device per sample"},
                 "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": traffic,
                              # the 157.3 TFLOP/s peak is one FMA (2 flops) per lane every 2 cycles; bit-exact parity keeps multiplies

@@ -226,7 +226,10 @@ typedef enum rt_render_flag {
     /* With accumulate == 0 the frame's linear value is still written to the accumulator (Renderer.accumulated,
      * src/renderer.rs:67-68) unless this flag is set: a caller that only displays `img` and never reads the accumulator
      * back saves 16 of the 20 bytes written per pixel.  Ignored when accumulate != 0. */
-    RT_RENDER_SKIP_ACCUM_STORE = 2
+    RT_RENDER_SKIP_ACCUM_STORE = 2,
+    /* rt_render_samples_device deals the tile rows to interleaved shares on streams of its own only for frames large enough
+     * to gain from it; this flag makes it do so whatever the frame size (tests of that path on small frames). */
+    RT_RENDER_SAMPLE_SHARES = 4
 } rt_render_flag;
 
 /* Creates a context bound to HIP device `device_id` (one context per GPU; one process per GPU
@@ -287,6 +290,15 @@ int32_t rt_render_device(rt_ctx *ctx, const rt_render_params *params, void *d_rg
  * and rt_get_stats must be read before the next such launch. */
 int32_t rt_render_device_noalloc(rt_ctx *ctx, const rt_render_params *params, void *d_rgba8, void *d_accum, void *stream);
 
+/* sample_count accumulating frames in one call: frame_index = params->frame_index, +1, ..., the pixels, accumulator and frame
+ * of that many rt_render_device calls (the loop of App3D::run around Renderer::render, src/app.rs:248 with
+ * src/renderer.rs:59-66, when a caller accumulates a fixed number of samples).  params->accumulate must be set;
+ * collect_events is not supported.  Large diffuse scenes are rendered as interleaved shares of the tile rows on streams of
+ * the library's own, which overlap; the caller's stream waits for them before it continues, so the call is asynchronous
+ * like rt_render_device.  Afterwards rt_get_stats reports the rays of the last sample. */
+int32_t rt_render_samples_device(rt_ctx *ctx, const rt_render_params *params, uint32_t sample_count, void *d_rgba8, void *d_accum,
+                                 void *stream);
+
 /* render_chunk's accumulation tail (src/renderer.rs:62-66) on its own: out = to_rgba(clamp(accum / sample_count, 0, 1))
  * for rows [row_begin, row_end) (0,0 = all).  Used when the samples of one frame were rendered by several GPUs and
  * their accumulators summed (all-reduce) outside this library; d_accum/d_rgba8 NULL = the context's own buffers. */
@@ -315,7 +327,6 @@ typedef struct rt_hierarchy_info {
 } rt_hierarchy_info;
 int32_t rt_get_hierarchy_info(rt_ctx *ctx, rt_hierarchy_info *out);
 
-/* Waits for the context's stream and sums the per-workgroup counters of the last render. */
 /* Self-check of the two transcendental functions the kernels share with every caller that wants bit-equal frames:
  * op RT_MATH_POWF: out[i] = powf(x[i], y[i]) as Ray::blinn_phong and the gamma steps evaluate it (f32::powf at src/ray.rs:81,
  * src/ray_tracing/ray_tracing.rs:55, src/ray_marching/ray_marching.rs:178); op RT_MATH_ATANF: out[i] = atanf(x[i]) (f32::atan at
@@ -324,6 +335,7 @@ int32_t rt_get_hierarchy_info(rt_ctx *ctx, rt_hierarchy_info *out);
 enum rt_math_op { RT_MATH_POWF = 0, RT_MATH_ATANF = 1 };
 int32_t rt_eval_math(rt_ctx *ctx, int32_t op, size_t n, const float *x, const float *y, float *out);
 
+/* Waits for the context's stream and sums the per-workgroup counters of the last render. */
 int32_t rt_get_stats(rt_ctx *ctx, rt_stats *out);
 
 /* The hipStream_t the context created for itself (rt_render runs on it).  No counterpart in the reference. */

@@ -31,7 +31,7 @@ RT_SPHERE, RT_TRIANGLE, RT_CUBOID, RT_PLANE, RT_CYLINDER, RT_CONE, RT_UNION, RT_
 RT_REFLECTIVE, RT_REFRACTIVE = 0, 1
 RT_DIRECTIONAL, RT_POSITIONAL, RT_SPHERICAL_POSITIONAL = 0, 1, 2
 RT_MATH_POWF, RT_MATH_ATANF = 0, 1
-RT_RENDER_ONE_LANE_PER_PIXEL, RT_RENDER_SKIP_ACCUM_STORE = 1, 2
+RT_RENDER_ONE_LANE_PER_PIXEL, RT_RENDER_SKIP_ACCUM_STORE, RT_RENDER_SAMPLE_SHARES = 1, 2, 4
 
 COUNTER_NAMES = [
     "rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "rays_march", "raygen",
@@ -134,7 +134,7 @@ ABI_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_set_scene", "rt_set_texture", "rt_set_camera", "rt_render", "rt_render_device",
     "rt_resolve_device", "rt_reset_accum", "rt_read_accum", "rt_get_stats", "rt_context_stream", "rt_device_rgba8", "rt_device_accum", "rt_last_error",
     "rt_abi_version", "rt_alloc_host_frame", "rt_free_host_frame", "rt_update_objects", "rt_read_ray_directions",
-    "rt_render_device_noalloc", "rt_get_hierarchy_info", "rt_eval_math",
+    "rt_render_device_noalloc", "rt_get_hierarchy_info", "rt_eval_math", "rt_render_samples_device",
 ]
 
 # RT_MI355X_LIB overrides the library file (used to A/B kernel builds); it is still a HIP build of this backend
@@ -175,6 +175,7 @@ def lib() -> C.CDLL:
         l.rt_free_host_frame.argtypes = [vp, C.c_void_p]; l.rt_free_host_frame.restype = C.c_int32
         l.rt_get_stats.argtypes = [vp, C.POINTER(rt_stats)]; l.rt_get_stats.restype = C.c_int32
         l.rt_get_hierarchy_info.argtypes = [vp, C.POINTER(rt_hierarchy_info)]; l.rt_get_hierarchy_info.restype = C.c_int32
+        l.rt_render_samples_device.argtypes = [vp, C.POINTER(rt_render_params), C.c_uint32, vp, vp, vp]; l.rt_render_samples_device.restype = C.c_int32
         l.rt_eval_math.argtypes = [vp, C.c_int32, C.c_size_t, vp, vp, vp]; l.rt_eval_math.restype = C.c_int32
         l.rt_context_stream.argtypes = [vp]; l.rt_context_stream.restype = vp
         l.rt_device_rgba8.argtypes = [vp]; l.rt_device_rgba8.restype = vp
@@ -392,6 +393,23 @@ class Context:
         fn = self._l.rt_render_device_noalloc if noalloc else self._l.rt_render_device
         self._check(fn(self._ctx, C.byref(p), C.c_void_p(d_rgba8 or None), C.c_void_p(d_accum or None), C.c_void_p(stream or None)),
                     "rt_render_device_noalloc" if noalloc else "rt_render_device")
+
+    def render_samples_device(self, first_frame_index: int, sample_count: int, seed: int = 0x5EED, rows: Optional[tuple] = None,
+                              d_rgba8: int = 0, d_accum: int = 0, stream: Optional[int] = None, tile_row_stride: int = 0, flags: int = 0):
+        """rt_render_samples_device: `sample_count` accumulating frames (frame_index = first_frame_index ...) in one call."""
+        p = rt_render_params()
+        p.frame_index = first_frame_index
+        p.accumulate = 1
+        p.no_timing = 1
+        p.seed = seed
+        if rows is not None:
+            p.row_begin, p.row_end = rows
+        p.tile_row_stride = tile_row_stride
+        p.flags = flags
+        if stream is None:
+            stream = int(self._l.rt_context_stream(self._ctx) or 0)
+        self._check(self._l.rt_render_samples_device(self._ctx, C.byref(p), sample_count, C.c_void_p(d_rgba8 or None), C.c_void_p(d_accum or None),
+                                                     C.c_void_p(stream or None)), "rt_render_samples_device")
 
     def resolve_device(self, sample_count: int, rows: Optional[tuple] = None, d_accum: int = 0, d_rgba8: int = 0, stream: Optional[int] = None):
         """rt_resolve_device: accumulated / sample_count -> clamp -> RGBA8 (after an external all-reduce of accumulators)."""

@@ -40,8 +40,11 @@ def interleaved_tile_rows(height: int, rank: int, world_size: int) -> List[Tuple
 
 
 def shard_samples(n_samples: int, rank: int, world_size: int, first_index: int = 1) -> List[int]:
-    """Sample (frame) indices rendered by `rank`: first_index + rank, + world_size, ... (interleaved)."""
-    return list(range(first_index + rank, first_index + n_samples, world_size))
+    """Sample (frame) indices rendered by `rank`: a contiguous block of the n_samples indices from first_index on (the first
+    n_samples % world_size ranks take one more), so that a rank renders its share with one rt_render_samples_device call."""
+    q, rem = divmod(n_samples, world_size)
+    begin = first_index + rank * q + min(rank, rem)
+    return list(range(begin, begin + q + (1 if rank < rem else 0)))
 
 
 def equal_row_bands(height: int, world_size: int) -> bool:

@@ -559,6 +559,71 @@ def test_regrouping_path_tracer_equals_the_one_lane_per_pixel_kernel(pkg, ctx, n
     assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[0], b[0])
 
 
+@pytest.mark.parametrize("name,size,samples", [("spheres1k", (640, 1024), 5), ("spheres1k", (200, 150), 4), ("spheres200", (64, 24), 3), ("spheres10k", (1920, 1080), 6),
+                                               ("scene2", (320, 240), 3), ("scene3", (160, 96), 2)])
+def test_sample_batch_equals_consecutive_renders(pkg, ctx, name, size, samples):
+    """rt_render_samples_device: N accumulating frames in one call (large diffuse scenes: interleaved shares of the tile rows
+    on the library's own streams) leave the accumulator, the frame and the ray count of N consecutive rt_render_device calls --
+    on the context's buffers and on caller buffers with a caller stream, for whole frames, a row range and an interleaved share,
+    and when a batch continues an earlier one."""
+    import torch
+    s = pkg.Scene(name)
+    if not s.desc.ray_marching:
+        s.desc.max_ray_bounces = 5
+    w, h = size
+    ctx.load(s, w, h)
+
+    def run(batched, rows=None, stride=0, first=1, n=samples, accum=None, rgba=None, stream=None):
+        if batched:
+            ctx.render_samples_device(first, n, seed=77, rows=rows, tile_row_stride=stride, d_rgba8=rgba.data_ptr() if rgba is not None else 0,
+                                      d_accum=accum.data_ptr() if accum is not None else 0, stream=stream, flags=pkg.RT_RENDER_SAMPLE_SHARES)
+        else:
+            for f in range(first, first + n):
+                ctx.render_device(frame_index=f, accumulate=True, seed=77, rows=rows, tile_row_stride=stride, d_rgba8=rgba.data_ptr() if rgba is not None else 0,
+                                  d_accum=accum.data_ptr() if accum is not None else 0, stream=stream)
+        return ctx.stats()["rays_total"]
+
+    # the context's own buffers and stream
+    got = {}
+    for batched in (False, True):
+        ctx.reset_accum()
+        rays = run(batched)
+        got[batched] = (ctx.read_accum(), rays)
+    assert got[True][1] == got[False][1] > 0
+    assert np.array_equal(got[True][0].view(np.uint32), got[False][0].view(np.uint32))
+    # caller buffers on a caller stream; a second batch continues the first; then a row range and an interleaved share
+    bufs = {}
+    side = torch.cuda.Stream()
+    for batched in (False, True):
+        rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        rays = [run(batched, accum=accum, rgba=rgba, stream=side.cuda_stream),
+                run(batched, first=samples + 1, n=2, accum=accum, rgba=rgba, stream=side.cuda_stream)]
+        if h >= 64:
+            rays.append(run(batched, rows=(16, h - 5), first=samples + 3, n=2, accum=accum, rgba=rgba, stream=side.cuda_stream))
+            rays.append(run(batched, rows=(8, h), stride=2, first=samples + 5, n=3, accum=accum, rgba=rgba, stream=side.cuda_stream))
+        side.synchronize()
+        bufs[batched] = (rgba.cpu().numpy(), accum.cpu().numpy(), rays)
+    assert bufs[True][2] == bufs[False][2]
+    assert np.array_equal(bufs[True][1].view(np.uint32), bufs[False][1].view(np.uint32)) and np.array_equal(bufs[True][0], bufs[False][0])
+
+
+def test_sample_batch_rejects_what_it_cannot_do(pkg, ctx):
+    l = pkg.lib()
+    ctx.load(pkg.Scene("scene3"), 64, 48)
+    p = pkg.rt_render_params()
+    p.frame_index = 1
+    assert l.rt_render_samples_device(ctx._ctx, C.byref(p), 4, None, None, None) == -1 and b"accumulate" in l.rt_last_error(ctx._ctx)
+    p.accumulate = 1
+    assert l.rt_render_samples_device(ctx._ctx, C.byref(p), 0, None, None, None) == -1
+    p.collect_events = 1
+    assert l.rt_render_samples_device(ctx._ctx, C.byref(p), 2, None, None, None) == -1
+    p.collect_events = 0
+    p.frame_index = 0
+    assert l.rt_render_samples_device(ctx._ctx, C.byref(p), 2, None, None, None) == -1
+
+
 def test_ten_thousand_sphere_scene_at_reduced_size(pkg, orc, ctx):
     """The 8K multi-sample workload's scene (10 000 spheres, diffuse, emissive every 16th) at a size the linear-scan
     oracle finishes in seconds: two accumulated samples, bit for bit."""

@@ -10,7 +10,7 @@ for lib in "$@"; do
               "SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_INSTS_VALU_CVT SQ_IFETCH SQ_INST_LEVEL_SMEM SQ_INSTS_SENDMSG SQ_LDS_BANK_CONFLICT"; do
     name=$(echo "$pass" | cut -d' ' -f1)
     d=gpurun_out/pmcab_${WL}_${tag}/$name; mkdir -p gpurun_out/pmcab_${WL}_${tag}
-    RT_MI355X_LIB=$PWD/$lib timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $d -- python3 bench.py --workload "$WL" --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $d.err || { echo "pass $name failed for $tag"; tail -2 $d.err; }
+    RT_MI355X_LIB=$PWD/$lib timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $d -- python3 bench.py --workload "$WL" --steps 4 --warmup 1 --no-cpu-baseline --consecutive-launches > /dev/null 2> $d.err || { echo "pass $name failed for $tag"; tail -2 $d.err; }
   done
   echo "== $tag"
   python3 - <<PY

@@ -10,7 +10,7 @@ for pass in "TA_TA_BUSY_sum TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_REA
             "TA_FLAT_READ_WAVEFRONTS_sum TA_TOTAL_WAVEFRONTS_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TOTAL_ACCESSES_sum TD_TD_BUSY_sum TD_TC_STALL_sum"; do
   name=$(echo "$pass" | cut -d' ' -f1)
   d=gpurun_out/pmcmem_${WL}_${tag}/$name; mkdir -p gpurun_out/pmcmem_${WL}_${tag}
-  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $d -- python3 bench.py --workload "$WL" --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $d.err || { echo "pass $name failed"; tail -2 $d.err; }
+  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $d -- python3 bench.py --workload "$WL" --steps 4 --warmup 1 --no-cpu-baseline --consecutive-launches > /dev/null 2> $d.err || { echo "pass $name failed"; tail -2 $d.err; }
 done
 python3 - <<PY
 import csv,glob,collections

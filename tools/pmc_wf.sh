@@ -10,7 +10,7 @@ for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
             "TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TOTAL_WRITE_sum TD_TD_BUSY_sum"; do
   name=$(echo "$pass" | cut -d' ' -f1)
   d=gpurun_out/pmcwf_${WL}_${tag}/$name; mkdir -p gpurun_out/pmcwf_${WL}_${tag}
-  timeout -s KILL 170 rocprofv3 --pmc $pass --output-format csv -d $d -- python3 bench.py --workload "$WL" --steps $STEPS --warmup 0 --no-cpu-baseline > /dev/null 2> $d.err || { echo "pass $name failed"; tail -2 $d.err; }
+  timeout -s KILL 170 rocprofv3 --pmc $pass --output-format csv -d $d -- python3 bench.py --workload "$WL" --steps $STEPS --warmup 0 --no-cpu-baseline --consecutive-launches > /dev/null 2> $d.err || { echo "pass $name failed"; tail -2 $d.err; }
 done
 python3 - <<PY
 import csv,glob,collections
