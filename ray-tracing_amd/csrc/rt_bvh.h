@@ -72,6 +72,25 @@ inline bool rt_object_bounds(const rt_object &o, RtAabb &b) {
     return true;
 }
 
+// DevObject::diag: a sphere whose transform and inv_transform both have, in their first three rows, non-zero finite
+// diagonal entries, a finite translation and (+-)0 everywhere else (what Sphere::new builds: no rotation,
+// src/utils/sphere.rs:26-37, :61-70).
+inline bool rt_object_is_diag_sphere(const rt_object &o) {
+    if (o.kind != RT_SPHERE) return false;
+    const float *ms[2] = {o.transform, o.inv_transform};
+    for (const float *m : ms)
+        for (int c = 0; c < 4; c++)
+            for (int r = 0; r < 3; r++) {
+                const float v = m[4 * c + r];
+                if (!std::isfinite(v)) return false;
+                if (c == r && v == 0.0f) return false;
+                if (c < 3 && c != r && v != 0.0f) return false;
+            }
+    return true;
+}
+// Kind code a hierarchy leaf carries for object `o` (see RT_LEAF_DIAG_SPHERE).
+inline int rt_leaf_kind(const rt_object &o) { return rt_object_is_diag_sphere(o) ? RT_LEAF_DIAG_SPHERE : (int)o.kind; }
+
 inline bool rt_bvh_wanted(const rt_scene_desc *d) {
     uint32_t bounded = 0;
     RtAabb b;
@@ -93,7 +112,7 @@ struct RtBvhBuilder {
     std::vector<uint32_t> ids;  // bounded object indices, permuted during the build
     std::vector<TreeNode> tree;
     std::vector<uint32_t> *prims;
-    std::vector<int> kinds;     // object kind by object index
+    std::vector<int> kinds;     // leaf kind code by object index (rt_leaf_kind)
     uint32_t max_depth = 0;     // 0: unlimited; else no leaf lies deeper than this many inner nodes below the root (see build)
 
     static float half_area(const RtAabb &b) {
@@ -196,7 +215,7 @@ inline void rt_bvh_build(const rt_scene_desc *d, std::vector<DevBvhNode> &nodes,
     B.prims = &prims;
     B.boxes.resize(d->n_objects);
     B.kinds.resize(d->n_objects);
-    for (uint32_t i = 0; i < d->n_objects; i++) B.kinds[i] = d->objects[i].kind;
+    for (uint32_t i = 0; i < d->n_objects; i++) B.kinds[i] = rt_leaf_kind(d->objects[i]);
     nodes.clear(); unbounded.clear();
     for (uint32_t i = 0; i < d->n_objects; i++) {
         if (rt_object_bounds(d->objects[i], B.boxes[i])) B.ids.push_back(i);
@@ -245,7 +264,7 @@ inline void rt_bvh2_build(const rt_scene_desc *d, RtBvh2 &out) {
     B.kinds.resize(d->n_objects);
     std::vector<uint32_t> ids;
     for (uint32_t i = 0; i < d->n_objects; i++) {
-        B.kinds[i] = d->objects[i].kind;
+        B.kinds[i] = rt_leaf_kind(d->objects[i]);
         if (rt_object_bounds(d->objects[i], B.boxes[i])) ids.push_back(i);
         else if (d->objects[i].kind == RT_PLANE) out.linear.push_back(i);
     }

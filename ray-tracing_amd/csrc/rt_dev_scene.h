@@ -19,6 +19,12 @@ struct DevObject {
     int32_t kind;      // rt_object_kind
     int32_t material;  // material index (0 for Union / Substraction)
     int32_t first, second;
+    // Bounding sphere flag of the linear scan's wave-level rejection test (bs below); 0 for planes and composites: never rejected.
+    int32_t bounded;
+    // Sphere whose transform and inv_transform have a diagonal 3x3 part with (+-)0 everywhere else (no rotation:
+    // Sphere::create, src/utils/sphere.rs:26-49): cand_sphere / fin_sphere then multiply by the diagonal only.
+    int32_t diag;
+    int32_t pad_[2];
     DevXform inv;  // inv_transform
     DevXform fwd;  // transform
     // kind-specific parameters:
@@ -29,11 +35,14 @@ struct DevObject {
     //   Triangle p[0..2] v1, p[3..5] v2, p[6..8] v3
     float p[12];
     // Bounding sphere of everything the object's intersect() can report (centre, squared radius with a safety margin), for
-    // the linear scan's wave-level rejection test; bounded == 0 (planes, composites): never rejected.
+    // the linear scan's wave-level rejection test (used when `bounded`).
     float bs[4];
-    int32_t bounded;
-    int32_t pad_[3];
 };
+
+// Kind code of a hierarchy leaf that holds a sphere with DevObject::diag set.  Leaves name their object's kind next to its
+// index; composites are never hit by rays (Ray::hit's `_ => None`, src/ray.rs:175) and never are leaves, so RT_UNION's code is
+// free there.
+#define RT_LEAF_DIAG_SPHERE 6
 
 struct DevMaterial {
     float ambience, diffuse, specular, shininess;

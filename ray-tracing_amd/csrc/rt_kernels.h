@@ -109,11 +109,33 @@ RT_DEV f3 tex_from_uv(const DevTexture &t, float u, float v) {
 // ------------------------------------------------------------------------------------------------
 // candidate phase of the Intersection impls: Some/None and `distance` only
 // ------------------------------------------------------------------------------------------------
+// The ray in the sphere's object space (src/utils/sphere.rs:103-105), with a = rd . rd and cc = ro . ro of the quadratic.
+// diag (DevObject::diag, spheres without rotation): the 3x3 part of inv_transform is diagonal and every other entry of its
+// first three rows is (+-)0, so a row of the reference's product, ((d * v.x + 0 * v.y) + 0 * v.z) + c, is d * v.x + c bit for
+// bit -- unless v has a non-finite component (0 * inf = NaN reaches every row) or the row's result is a zero (the sign of a
+// zero sum depends on the signs of the zero terms).  Either case shows in values computed anyway: a non-finite component of
+// v makes its own row, and with it a or cc, non-finite.  Such lanes take the full product.  Returns whether the short form held.
+RT_DEV bool sphere_local_ray(const DevObject &o, bool diag, f3 ro_w, f3 rd_w, f3 &ro, f3 &rd, float &a, float &cc) {
+    if (diag) {
+        rd = mk3(o.inv.c0[0] * rd_w.x, o.inv.c1[1] * rd_w.y, o.inv.c2[2] * rd_w.z);
+        ro = mk3(o.inv.c0[0] * ro_w.x + o.inv.c3[0], o.inv.c1[1] * ro_w.y + o.inv.c3[1], o.inv.c2[2] * ro_w.z + o.inv.c3[2]);
+        a = dot(rd, rd);
+        cc = dot(ro, ro);
+        const float smallest = rt_min(rt_min(rt_min(rt_abs(rd.x), rt_abs(rd.y)), rt_abs(rd.z)), rt_min(rt_min(rt_abs(ro.x), rt_abs(ro.y)), rt_abs(ro.z)));
+        if (smallest > 0.0f && a + cc < __builtin_inff()) return true;   // a, cc >= 0, or NaN
+    }
+    rd = xf_dir(o.inv, rd_w); ro = xf_pt(o.inv, ro_w);
+    a = dot(rd, rd);
+    cc = dot(ro, ro);
+    return false;
+}
+template <bool DIAG = false>
 RT_DEV bool cand_sphere(const DevObject &o, f3 ro_w, f3 rd_w, float &t) {  // src/utils/sphere.rs:99-125
-    f3 rd = xf_dir(o.inv, rd_w), ro = xf_pt(o.inv, ro_w);
-    float a = dot(rd, rd);
+    f3 rd, ro;
+    float a, cc;
+    sphere_local_ray(o, DIAG, ro_w, rd_w, ro, rd, a, cc);
     float b = 2.0f * dot(ro, rd);
-    float c = dot(ro, ro) - 1.0f;
+    float c = cc - 1.0f;
     float disc = b * b - 4.0f * a * c;
     if (disc < 0.0f) return false;
     t = (-b - rt_sqrt(disc)) / (2.0f * a);
@@ -244,7 +266,7 @@ RT_DEV int trace_closest(const DevScene &S, f3 ro, f3 rd, float &t_out, int &sub
         int sub = 0;
         bool ok = false;
         switch (o.kind) {
-            case RT_SPHERE: cnt.add(RT_CNT_TEST_SPHERE); ok = cand_sphere(o, ro, rd, t); break;
+            case RT_SPHERE: cnt.add(RT_CNT_TEST_SPHERE); ok = o.diag ? cand_sphere<true>(o, ro, rd, t) : cand_sphere<false>(o, ro, rd, t); break;
             case RT_TRIANGLE: if (!SP) { cnt.add(RT_CNT_TEST_TRIANGLE); ok = cand_triangle(o, ro, rd, t); } break;
             case RT_CUBOID: if (!SP) { cnt.add(RT_CNT_TEST_CUBOID); ok = cand_cuboid(o, ro, rd, t); } break;
             case RT_PLANE: cnt.add(RT_CNT_TEST_PLANE); ok = cand_plane(o, ro, rd, t); break;
@@ -260,11 +282,14 @@ RT_DEV int trace_closest(const DevScene &S, f3 ro, f3 rd, float &t_out, int &sub
 }
 
 // One candidate test with a per-lane object (the object index differs between lanes: vector loads, divergent switch).
+// `kind` comes from a hierarchy leaf: the object's kind, or RT_LEAF_DIAG_SPHERE for a sphere with DevObject::diag set
+// (composites never are leaves, so their codes are free there).
 template <bool EVENTS>
 RT_DEV bool cand_any(int kind, const DevObject &o, f3 ro, f3 rd, float &t, int &sub, Cnt<EVENTS> &cnt) {
     sub = 0;
     switch (kind) {
-        case RT_SPHERE: cnt.add(RT_CNT_TEST_SPHERE); return cand_sphere(o, ro, rd, t);
+        case RT_SPHERE: cnt.add(RT_CNT_TEST_SPHERE); return cand_sphere<false>(o, ro, rd, t);
+        case RT_LEAF_DIAG_SPHERE: cnt.add(RT_CNT_TEST_SPHERE); return cand_sphere<true>(o, ro, rd, t);
         case RT_TRIANGLE: cnt.add(RT_CNT_TEST_TRIANGLE); return cand_triangle(o, ro, rd, t);
         case RT_CUBOID: cnt.add(RT_CNT_TEST_CUBOID); return cand_cuboid(o, ro, rd, t);
         case RT_PLANE: cnt.add(RT_CNT_TEST_PLANE); return cand_plane(o, ro, rd, t);
@@ -331,9 +356,22 @@ RT_DEV int trace_ray(const DevScene &S, f3 ro, f3 rd, float &t_out, int &sub_out
 // finalise phase: RayHit of the closest candidate, same arithmetic as the reference's intersect()
 // ------------------------------------------------------------------------------------------------
 RT_DEV void fin_sphere(const DevObject &o, f3 ro_w, f3 rd_w, float t1, bool need_uv, HitRec &h) {  // sphere.rs:127-146
-    f3 rd = xf_dir(o.inv, rd_w), ro = xf_pt(o.inv, ro_w);
+    f3 rd, ro;
+    float a_unused, cc_unused;
+    const bool diag = o.diag != 0;
+    const bool short_form = sphere_local_ray(o, diag, ro_w, rd_w, ro, rd, a_unused, cc_unused);
     f3 l = ro + rd * t1;
-    h.normal = normalize(xf_dir(o.fwd, l));
+    // the normal's transform by the diagonal, under the same two conditions (ro, rd and t1 are finite here, so a component
+    // of l is finite or an infinity, never a NaN)
+    f3 n = splat3(0.0f);
+    bool n_done = false;
+    if (short_form) {
+        n = mk3(o.fwd.c0[0] * l.x, o.fwd.c1[1] * l.y, o.fwd.c2[2] * l.z);
+        const float n_min = rt_min(rt_min(rt_abs(n.x), rt_abs(n.y)), rt_abs(n.z)), n_max = rt_max(rt_max(rt_abs(n.x), rt_abs(n.y)), rt_abs(n.z));
+        n_done = n_min > 0.0f && n_max < __builtin_inff();
+    }
+    if (!n_done) n = xf_dir(o.fwd, l);
+    h.normal = normalize(n);
     h.point = ro_w + rd_w * t1;
     if (need_uv) {
         float u = rt_atanf((l.x * l.x + l.y * l.y) / l.z);

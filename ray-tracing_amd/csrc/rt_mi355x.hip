@@ -174,7 +174,7 @@ DevObject make_dev_object(const rt_object &o) {
     g.inv = make_xform(o.inv_transform);
     g.fwd = make_xform(o.transform);
     switch (o.kind) {
-        case RT_SPHERE: g.p[0] = o.radius; break;
+        case RT_SPHERE: g.p[0] = o.radius; g.diag = rt_object_is_diag_sphere(o) ? 1 : 0; break;
         case RT_CUBOID:
             for (int k = 0; k < 3; k++) {
                 g.p[k] = o.dimension[k];
