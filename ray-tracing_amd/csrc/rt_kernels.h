@@ -631,6 +631,30 @@ RT_DEV void store_pixel(const DevFrame &F, uint32_t pos, f3 p) {
     uint32_t r = rt_as_u8(c.x * 255.0f), g = rt_as_u8(c.y * 255.0f), b = rt_as_u8(c.z * 255.0f), a8 = rt_as_u8(c.w + 255.0f);
     __builtin_nontemporal_store(r | (g << 8) | (b << 16) | (a8 << 24), &F.rgba[pos]);
 }
+// The same in two steps for a lane with several pixels: load_accum for all of them first, so that every accumulator load
+// is in flight before the first dependent store, then store_pixel with the loaded entry.
+RT_DEV float4 load_accum(const DevFrame &F, uint32_t pos) {
+    if (F.accumulate) return reinterpret_cast<const float4 *>(F.accum)[pos];
+    return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+RT_DEV void store_pixel(const DevFrame &F, uint32_t pos, f3 p, float4 a) {
+    float4 *acc = reinterpret_cast<float4 *>(F.accum) + pos;
+    float4 c;
+    if (F.accumulate) {
+        a.x = a.x + p.x; a.y = a.y + p.y; a.z = a.z + p.z; a.w = a.w + 1.0f;
+        *acc = a;
+        float fi = (float)F.frame_index;
+        c.x = rt_clamp01_sse(a.x / fi); c.y = rt_clamp01_sse(a.y / fi); c.z = rt_clamp01_sse(a.z / fi); c.w = rt_clamp01_sse(a.w / fi);
+    } else {
+        c.x = rt_clamp01_sse(p.x); c.y = rt_clamp01_sse(p.y); c.z = rt_clamp01_sse(p.z); c.w = rt_clamp01_sse(1.0f);
+        if (!F.skip_accum_store) {
+            __builtin_nontemporal_store(c.x, &acc->x); __builtin_nontemporal_store(c.y, &acc->y);
+            __builtin_nontemporal_store(c.z, &acc->z); __builtin_nontemporal_store(c.w, &acc->w);
+        }
+    }
+    uint32_t r = rt_as_u8(c.x * 255.0f), g = rt_as_u8(c.y * 255.0f), b = rt_as_u8(c.z * 255.0f), a8 = rt_as_u8(c.w + 255.0f);
+    __builtin_nontemporal_store(r | (g << 8) | (b << 16) | (a8 << 24), &F.rgba[pos]);
+}
 
 // The workgroup's row in the counter table (2-D grid, see lane_pixel).
 RT_DEV uint32_t rt_block_index() { return blockIdx.y * gridDim.x + blockIdx.x; }
@@ -726,6 +750,31 @@ __global__ void __launch_bounds__(256, BVH ? 5 : (REFR ? RT_REFR_WAVES : 7)) rt_
         int ray_slot = RT_CNT_RAYS_PRIMARY;
         float rfr[REFR ? RDEPTH : 1][16];
         bool done = false;
+        if (!REFR && scene_diffuse) {
+            // color_diffuse without refractive materials: every node of the recursion has one child and returns that child's
+            // value unchanged (ray_tracing.rs:111-114), so a path is a forward loop without frames.
+            for (;;) {
+                if (depth >= maxd) { V = L; break; }
+                float t; int sub;
+                const int obj = trace_ray<EVENTS, BVH, SP>(S, ro, rd, t, sub, cnt, ray_slot);
+                if (obj < 0) { V = L + ambient * Cc; break; }
+                HitRec h; Mtl m;
+                finalize_hit<EVENTS, BVH, SP>(S, ro, rd, t, obj, sub, h, m, cnt);
+                if (m.kind != RT_REFLECTIVE) { V = splat3(0.0f); break; }   // unreachable: REFR is set whenever a refractive material exists
+                f3 albedo = m.albedo;
+                if (m.texture >= 0) { cnt.add(RT_CNT_TEX_FETCH); albedo = tex_from_uv(S.textures[m.texture], h.u, h.v); }
+                const f3 p = L + m.emission_power * albedo;
+                cnt.add(RT_CNT_DIFFUSE_RAY);
+                f3 no, nd;
+                rt_reflection_ray(rd, h, m.roughness, key, true, jitter, no, nd);
+                cnt.add(RT_CNT_COMBINE_REFL);
+                ro = no; rd = nd; L = p; Cc = Cc * albedo;
+                key = rt_rng_child_key(key, 0u);
+                depth += 1u;
+                ray_slot = RT_CNT_RAYS_REFLECTION;
+            }
+            done = true;
+        }
         while (!done) {
             bool have_value = false;
             // ---- descend: evaluate color / color_diffuse at (ro, rd, depth, L, Cc)

@@ -601,6 +601,13 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
     // (rt_wavefront.h).  The counting variant, the no-alloc entry point and the A/B flag keep the one-lane-per-pixel kernel.
     const bool regroup = !S.ray_marching && S.bvh2_nodes && S.diffuse && !c->has_refractive && maxd >= 1u && !events && !noalloc &&
                          !(p->flags & RT_RENDER_ONE_LANE_PER_PIXEL);
+    // Small diffuse scenes (linear scan) without refractive materials: lanes take the strip's next pixel when their path ends
+    const bool refill = !regroup && !S.ray_marching && !S.bvh_nodes && S.diffuse && !c->has_refractive && maxd >= 1u && !events &&
+                        !(p->flags & RT_RENDER_ONE_LANE_PER_PIXEL);
+    if (refill) {
+        grid = dim3((tiles_x + kRfTiles - 1u) / kRfTiles, tiles_y);
+        blocks = grid.x * grid.y;
+    }
     WfArgs W = {};
     if (regroup) {
         { const int32_t r = query_wf_groups(c); if (r != RT_OK) return r; }
@@ -687,6 +694,9 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
             for (int i = 0; i < WS_N; i++) fprintf(stderr, "WFSTAT %-14s runs %12llu lanes %14llu  mean lanes %5.1f\n", names[i], h[2 * i], h[2 * i + 1], h[2 * i] ? (double)h[2 * i + 1] / (double)h[2 * i] : 0.0);
         }
 #endif
+    } else if (refill) {
+        if (c->spheres_planes_only) launch(rt_refill_diffuse_kernel<true>, grid, 64u, 0, s, S, c->camera, F);
+        else launch(rt_refill_diffuse_kernel<false>, grid, 64u, 0, s, S, c->camera, F);
     } else if (S.ray_marching) {
         // up to 16 leaves (12.5 KiB of LDS per 64-thread workgroup) keep their object-space rays in LDS during the march loop
         const bool cache = c->leaf_slots >= 1u && c->leaf_slots <= (uint32_t)RT_MARCH_CACHE_MAX_SLOTS;

@@ -383,6 +383,114 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_diffuse_kernel(const De
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small diffuse scenes (linear scan): lanes that take the next pixel when their path ends.
+//
+// Same function as above -- color_diffuse's forward loop -- for scenes whose closest hits come from the wave-uniform scan
+// over all objects.  There the scan itself keeps every lane busy whatever ray it holds, so paths need not be stored and
+// re-grouped between bounces: a wavefront owns a strip of kRfTiles 8x8 tiles, every lane follows one path at a time in
+// registers, and a lane whose path has ended (miss, or depth limit) writes its pixel and takes the strip's next pixel.
+// One loop iteration is one trace_ray + shading step for all lanes, each at its own depth.  With one pixel per lane for the
+// whole launch, a wavefront ran as long as its longest path (up to max_ray_bounces) while most paths end after one or two rays.
+// Every path does the arithmetic it does in rt_trace_kernel, in the same order: frames are bit-identical.
+// ------------------------------------------------------------------------------------------------
+#ifndef RT_RF_TILES
+#define RT_RF_TILES 4
+#endif
+#ifndef RT_RF_MIN_IDLE
+#define RT_RF_MIN_IDLE 16    // idle lanes that trigger a refill
+#endif
+constexpr uint32_t kRfTiles = RT_RF_TILES;
+
+template <bool SP>
+__global__ void __launch_bounds__(64, 8) rt_refill_diffuse_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
+    // value of every finished path, by slot; the strip's pixels are written in one pass at the end, whole tiles at a time
+    // (a store per finished path would put an accumulator read-modify-write round trip into every iteration of the loop)
+    __shared__ float s_val[3u * kRfTiles * 64u];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t ty = gridDim.y - 1u - blockIdx.y;   // tile rows from the bottom of the band up, as lane_pixel
+    const uint32_t x0 = blockIdx.x * kRfTiles * 8u, y0 = F.row_begin + ty * F.tile_row_step;
+    const uint32_t n = kRfTiles * 64u;
+    const uint32_t maxd = S.max_ray_bounces;
+    const f3 ambient = ld3(S.ambient);
+    const bool jitter = S.enable_accumulation != 0u;
+    Cnt<false> cnt;
+    cnt.clear();
+    uint32_t next = 0u;          // wave-uniform: first slot of the strip not handed out yet
+    bool have = false;           // this lane holds a path
+    bool first = true;           // wave-uniform: every ray of this iteration is a camera ray
+    uint32_t slot = 0u, key = 0u, depth = 0u;
+    f3 ro = splat3(0.0f), rd = splat3(0.0f), L = splat3(0.0f), Cc = splat3(1.0f);
+    for (;;) {
+        const uint64_t idle = __ballot(!have);
+        if (next < n && ((uint32_t)__popcll(idle) >= (uint32_t)RT_RF_MIN_IDLE)) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            if (!have) {
+                const uint32_t j = next + rank;
+                uint32_t pos;
+                if (j < n && wf_slot_pixel(C, F, x0, y0, j, pos)) {
+                    have = true;
+                    slot = j;
+                    ro = ld3(C.position); rd = ld3(C.ray_dirs + 3u * (size_t)pos);
+                    L = splat3(0.0f); Cc = splat3(1.0f);
+                    key = rt_rng_path_key(F.seed, pos, F.frame_index);
+                    depth = 0u;
+                }
+            }
+            const uint32_t take = (uint32_t)__popcll(idle);
+            next = (n - next < take) ? n : next + take;
+        }
+        if (__ballot(have) == 0ull) {
+            if (next >= n) break;
+            continue;   // only slots outside the frame were handed out
+        }
+        if (have) {
+            float t; int sub;
+            const int obj = trace_closest<false, SP>(S, ro, rd, t, sub, cnt, first ? RT_CNT_RAYS_PRIMARY : RT_CNT_RAYS_REFLECTION);
+            f3 V = L + ambient * Cc;   // the value of a miss
+            bool ended = true;
+            if (obj >= 0) {
+                HitRec h; Mtl m;
+                finalize_hit<false, false, SP>(S, ro, rd, t, obj, sub, h, m, cnt);
+                f3 albedo = m.albedo;
+                if (m.texture >= 0) albedo = tex_from_uv(S.textures[m.texture], h.u, h.v);
+                const f3 p = L + m.emission_power * albedo;
+                V = p;                      // the child at the depth limit returns its light_color (ray_tracing.rs:83-85)
+                if (depth + 1u < maxd) {
+                    f3 no, nd;
+                    rt_reflection_ray(rd, h, m.roughness, key, true, jitter, no, nd);
+                    ro = no; rd = nd; L = p; Cc = Cc * albedo;
+                    key = rt_rng_child_key(key, 0u);
+                    depth += 1u;
+                    ended = false;
+                }
+            }
+            if (ended) {
+                s_val[slot] = V.x; s_val[n + slot] = V.y; s_val[2u * n + slot] = V.z;
+                have = false;
+            }
+        }
+        first = false;
+    }
+    __syncthreads();
+    float4 acc[kRfTiles];
+#pragma unroll
+    for (uint32_t k = 0u; k < kRfTiles; k++) {   // every accumulator load of the strip is in flight before the first store
+        uint32_t pos;
+        acc[k] = wf_slot_pixel(C, F, x0, y0, k * 64u + lane, pos) ? load_accum(F, pos) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+#pragma unroll
+    for (uint32_t k = 0u; k < kRfTiles; k++) {
+        const uint32_t j = k * 64u + lane;
+        uint32_t pos;
+        if (wf_slot_pixel(C, F, x0, y0, j, pos)) store_pixel(F, pos, mk3(s_val[j], s_val[n + j], s_val[2u * n + j]), acc[k]);
+    }
+    uint32_t rays = cnt.rays;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_xor(rays, off, 64);
+    if (lane == 0u) F.counters[rt_block_index()] = rays;
+}
+
 // Chooses the tile-row order of the next rt_wf_diffuse_kernel launch and resets its work counter (one workgroup).
 // Measured on the 10 000-sphere frame: which rows run first and last matters by 6 % -- starting every wavefront on the most
 // expensive rows at once is the slowest order, ending on them leaves the chip half empty while the last tiles finish, and

@@ -530,13 +530,17 @@ def test_hierarchy_traversal_equals_linear_scan_on_sphere_fields(pkg, orc, ctx, 
 
 
 @pytest.mark.parametrize("size", [(7, 5), (64, 8), (65, 9), (200, 150), (1000, 300)])
-@pytest.mark.parametrize("name,bounces", [("spheres1k", 5), ("spheres200", 1), ("spheres200", 9)])
+@pytest.mark.parametrize("name,bounces", [("spheres1k", 5), ("spheres200", 1), ("spheres200", 9), ("scene2", 5), ("scene2", 1), ("tex4+diffuse", 6),
+                                          ("scene3+diffuse", 3)])
 def test_regrouping_path_tracer_equals_the_one_lane_per_pixel_kernel(pkg, ctx, name, bounces, size):
-    """Large diffuse scenes run on persistent wavefronts that re-group their rays between bounces; the flag
-    RT_RENDER_ONE_LANE_PER_PIXEL selects the plain kernel.  Same paths, same arithmetic: accumulator, bytes and ray count
-    are identical, for whole frames, row ranges and interleaved shares, over three accumulated samples."""
+    """Diffuse scenes without refractive materials do not keep one pixel per lane: large ones run on persistent wavefronts
+    that re-group their rays between bounces, small ones (linear scan) on lanes that take their strip's next pixel when a
+    path ends.  The flag RT_RENDER_ONE_LANE_PER_PIXEL selects the plain kernel.  Same paths, same arithmetic: accumulator,
+    bytes and ray count are identical, for whole frames, row ranges and interleaved shares, over three accumulated samples."""
     import torch
-    s = pkg.Scene(name)
+    s = pkg.Scene(name.split("+")[0])
+    if name.endswith("+diffuse"):
+        s.desc.diffuse = 1
     s.desc.max_ray_bounces = bounces
     w, h = size
     ctx.load(s, w, h)
