@@ -376,8 +376,8 @@ def kernel_name(pkg, scene) -> str:
         return "rt_march_kernel"
     refractive = any(d.materials[i].kind == pkg.RT_REFRACTIVE for i in range(d.n_materials))
     bounded = sum(1 for i in range(d.n_objects) if d.objects[i].kind not in (pkg.RT_PLANE, pkg.RT_UNION, pkg.RT_SUBSTRACTION))
-    if d.diffuse and not refractive and bounded >= 32 and d.max_ray_bounces >= 1:
-        return "rt_wf_diffuse_kernel"
+    if d.diffuse and not refractive and d.max_ray_bounces >= 1:
+        return "rt_wf_diffuse_kernel" if bounded >= 32 else "rt_refill_diffuse_kernel"
     return "rt_trace_kernel"
 
 

@@ -219,9 +219,10 @@ typedef struct rt_render_params {
 
 /* rt_render_params.flags.  Neither flag changes a pixel. */
 typedef enum rt_render_flag {
-    /* Large diffuse scenes (hierarchy in use, Scene.diffuse set, no refractive material) are normally traced by the
-     * kernel that re-groups rays between bounces; this flag selects the one-lane-per-pixel kernel instead (A/B runs
-     * and tests that compare the two). */
+    /* Diffuse scenes (Scene.diffuse set, no refractive material) are normally traced by kernels that do not keep one
+     * pixel per lane for a whole path: large scenes (hierarchy in use) by the kernel that re-groups rays between bounces,
+     * small ones by the kernel whose lanes take the next pixel when their path ends.  This flag selects the
+     * one-lane-per-pixel kernel instead (A/B runs and tests that compare the two). */
     RT_RENDER_ONE_LANE_PER_PIXEL = 1,
     /* With accumulate == 0 the frame's linear value is still written to the accumulator (Renderer.accumulated,
      * src/renderer.rs:67-68) unless this flag is set: a caller that only displays `img` and never reads the accumulator

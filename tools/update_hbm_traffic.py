@@ -22,8 +22,8 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RENDER_KERNELS = ("rt_trace_kernel<false", "rt_march_kernel<false", "rt_wf_")   # timed variants; the counting variants are <true, ...>
-ONCE_PER_CALL = ("rt_trace_kernel<false", "rt_march_kernel<false", "rt_wf_diffuse_kernel")
+RENDER_KERNELS = ("rt_trace_kernel<false", "rt_march_kernel<false", "rt_wf_", "rt_refill_diffuse_kernel")   # timed variants; the counting variants are <true, ...>
+ONCE_PER_CALL = ("rt_trace_kernel<false", "rt_march_kernel<false", "rt_wf_diffuse_kernel", "rt_refill_diffuse_kernel")
 
 
 def sha256(path):
