@@ -831,6 +831,48 @@ def test_random_scenes_through_the_hierarchy(pkg, orc, ctx, seed):
     assert np.array_equal(ctx.read_accum().view(np.uint32), lin.view(np.uint32))
 
 
+@pytest.mark.parametrize("mode", ["whitted", "diffuse"])
+@pytest.mark.parametrize("many", [False, True])
+def test_unrotated_textured_spheres_on_the_camera_axes(pkg, orc, ctx, mode, many):
+    """Spheres without rotation take a short form of their transforms and fall back to the full products, lane by lane, when
+    a row of the short form is a zero.  Here those lanes exist in every frame: the camera sits on the z axis (origin
+    components 0), the frame has an even width and height (a centre column and a centre row of rays with a direction
+    component of exactly 0), spheres are centred on the axes and on the camera's own x / y, next to one rotated sphere (full
+    products throughout), and all of them are textured (UVs from atan of object-space coordinates, zeros included).  Small
+    scene: the linear scan; 47 spheres: the hierarchy kernels (leaves that name such spheres by their own kind code).
+    Whitted and diffuse modes, two accumulated frames; bit-exact against the oracle, which always forms the full products."""
+    mats = [make_material(pkg, albedo=(0.6, 0.6, 0.6), texture=t, roughness=0.6, ambience=0.5, emission_power=1.5) for t in range(4)]
+    mats.append(make_material(pkg, albedo=(0.7, 0.7, 0.7), roughness=1.0, emission_power=0.5))
+    objs = [make_object(pkg, pkg.RT_PLANE, 4, normal=(0, 1, 0), point=(0, -1.0, 0), max_dist=(30.0, 30.0), has_max_dist=1),
+            make_object(pkg, pkg.RT_SPHERE, 0, position=(0.0, 0.0, 0.0), radius=1.0),
+            make_object(pkg, pkg.RT_SPHERE, 1, position=(0.0, 1.75, -1.0), radius=0.75),
+            make_object(pkg, pkg.RT_SPHERE, 2, position=(-2.0, 0.0, 0.0), radius=0.5),
+            make_object(pkg, pkg.RT_SPHERE, 3, position=(2.5, 0.0, -3.0), rotation_axis=(30.0, 0.0, 0.0), radius=1.0)]
+    if many:
+        for ix in range(-3, 4):
+            for iz in range(6):
+                objs.append(make_object(pkg, pkg.RT_SPHERE, (ix + iz) % 4, position=(1.25 * ix, -0.6, -4.0 - 1.25 * iz), radius=0.4))
+    lights = [make_light(pkg, pkg.RT_POSITIONAL, (1, 1, 1), (0.0, 6.0, 4.0), 30.0), make_light(pkg, pkg.RT_DIRECTIONAL, (1, 0.9, 0.8), (0.0, -1.0, -0.5), 0.6)]
+    sb = SceneBuilder(pkg, objs, mats, lights, n_textures=4, max_ray_bounces=4, shadow_casting=1, diffuse=1 if mode == "diffuse" else 0,
+                      ambient_color=(0.1, 0.12, 0.2))
+    cam = pkg.make_camera((0.0, 0.0, 6.0), (0.0, 0.0, -1.0), 128, 96)
+    tex = pkg.load_textures()
+    for i, t in enumerate(tex):
+        ctx.set_texture(i, t)
+    ctx.set_scene(sb.desc)
+    ctx.set_camera(cam)
+    dirs = ctx.read_ray_directions()
+    assert (dirs[:, 64, 0] == 0.0).all() and (dirs[48, :, 1] == 0.0).all()      # the centre column and row exist
+    acc = np.zeros((96, 128, 4), dtype=np.float32)
+    for f in (1, 2):
+        rgba = ctx.render(frame_index=f, accumulate=True, reset_accum=(f == 1), seed=3)
+        ref = orc.render(sb.desc, cam, tex, frame_index=f, accumulate=True, seed=3, accum=acc, n_threads=8)
+        assert_parity(rgba, ref["rgba"], ctx.read_accum(), acc, what=f"axis-centred spheres, {mode}, frame {f}")
+    info = ctx.hierarchy_info() if hasattr(ctx, "hierarchy_info") else None
+    if info is not None:
+        assert bool(info["stackless_nodes"]) == many
+
+
 @pytest.mark.parametrize("seed", list(range(8)))
 def test_random_diffuse_scenes_through_the_regrouping_path_tracer(pkg, orc, ctx, seed):
     """Random diffuse (emissive) scenes of 40-90 objects of every primitive kind, rotated and overlapping, with exact
