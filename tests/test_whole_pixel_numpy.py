@@ -2,7 +2,8 @@
 
 The reference holds no vectors to pin the oracle with, so a second restatement of the per-pixel function, written from
 the Rust sources in another language and style, stands in: camera ray, closest hit, both shadow rays, Blinn-Phong, gamma,
-the reflection chain (scene3), and march, normal, occlusion, tri-planar texture, fade (scene4).  Agreement is to the
+the reflection chain (scene3), the Refractive arm with Fresnel weight, refraction ray and total internal reflection (a scene
+with two glass spheres), and march, normal, occlusion, tri-planar texture, fade (scene4).  Agreement is to the
 accuracy of the transcendental functions (numpy's powf here, a specified algorithm in the oracle): 2e-5 absolute on the
 linear value, one step on the bytes.  PARITY UNPINNED against reference outputs all the same.
 """
@@ -10,6 +11,7 @@ import numpy as np
 import pytest
 
 import whole_pixel_numpy as wp
+from helpers import SceneBuilder, make_light, make_material, make_object
 
 
 def _pick(mask, n, rng):
@@ -42,6 +44,48 @@ def test_whitted_pixels_of_the_default_scene(pkg, orc, bounces):
         assert np.allclose(p, lin[y, x, :3], rtol=2e-5, atol=2e-5), f"pixel ({x}, {y}): numpy {p}, oracle {lin[y, x, :3]}"
         assert np.abs(wp.to_rgba(p).astype(int) - ref["rgba"][y, x].astype(int)).max() <= 1
     assert tracer.rays > len(pixels) * 2   # shadow and reflection rays were traced
+
+
+def test_whitted_pixels_through_glass(pkg, orc):
+    """The Refractive arm of RayTracing::color (src/ray_tracing/ray_tracing.rs:197-236), Material::fresnel and
+    Ray::refraction_ray re-derived in numpy: a plane, two opaque spheres and two glass spheres (refraction index above and
+    below 1: entering, leaving, the n1 > n2 branch of fresnel and total internal reflection), two lights with shadows."""
+    mats = [make_material(pkg, albedo=(0.5, 0.5, 0.5), roughness=0.7, ambience=0.5, shininess=8.0, specular=0.6),
+            make_material(pkg, albedo=(0.9, 0.3, 0.2), roughness=0.4, ambience=0.4, shininess=40.0, specular=1.0),
+            make_material(pkg, albedo=(0.95, 0.97, 1.0), kind=pkg.RT_REFRACTIVE, transparency=0.9, refraction_index=1.5, reflectivity=0.1, ambience=0.3),
+            make_material(pkg, albedo=(0.8, 1.0, 0.8), kind=pkg.RT_REFRACTIVE, transparency=0.8, refraction_index=0.8, reflectivity=0.2, ambience=0.3)]
+    objs = [make_object(pkg, pkg.RT_PLANE, 0, normal=(0, 1, 0), point=(0, -0.5, 0), max_dist=(8.0, 8.0), has_max_dist=1),
+            make_object(pkg, pkg.RT_SPHERE, 1, position=(-1.4, 0.1, -1.0), radius=0.6),
+            make_object(pkg, pkg.RT_SPHERE, 2, position=(0.0, 0.2, 0.8), radius=0.7),
+            make_object(pkg, pkg.RT_SPHERE, 3, position=(1.5, 0.1, 0.2), radius=0.6),
+            make_object(pkg, pkg.RT_SPHERE, 1, position=(0.6, 0.0, -2.2), rotation_axis=(20.0, 40.0, 0.0), radius=0.5)]
+    lights = [make_light(pkg, pkg.RT_POSITIONAL, (1, 1, 1), (2.0, 5.0, 4.0), 25.0), make_light(pkg, pkg.RT_DIRECTIONAL, (0.8, 0.9, 1.0), (-0.3, -1.0, -0.4), 0.7)]
+    sb = SceneBuilder(pkg, objs, mats, lights, max_ray_bounces=4, shadow_casting=1, ambient_color=(0.1, 0.15, 0.3))
+    w, h = 128, 96
+    cam = pkg.make_camera((0.2, 1.0, 4.5), (0.0, -0.15, -1.0), w, h)
+    ref = orc.render(sb.desc, cam, (), n_threads=4, want_linear=True, want_counters=True)
+    lin = ref["linear"]
+    counters = dict(zip(pkg.COUNTER_NAMES, ref["counters"]))
+    assert counters["refraction"] > 500
+    tracer = wp.Whitted(pkg, sb.desc)
+    # pixels whose camera ray meets glass first, found with the numpy tracer's own closest hit; and some that do not
+    glass, other = [], []
+    rng = np.random.default_rng(3)
+    for _ in range(4000):
+        x, y = int(rng.integers(0, w)), int(rng.integers(0, h))
+        hit = tracer.trace_ray(*wp.camera_ray(cam, x, y))
+        first = None if hit is None else sb.desc.objects[hit[1]].material_index
+        (glass if first in (2, 3) else other).append((x, y, first))
+        if len(glass) >= 40 and len(other) >= 8:
+            break
+    n2 = [g for g in glass if g[2] == 2][:14]
+    n3 = [g for g in glass if g[2] == 3][:14]
+    assert len(n2) >= 8 and len(n3) >= 8
+    for x, y, _ in n2 + n3 + other[:8]:
+        p = tracer.pixel(cam, x, y)
+        assert np.allclose(p, lin[y, x, :3], rtol=5e-5, atol=3e-5), f"pixel ({x}, {y}): numpy {p}, oracle {lin[y, x, :3]}"
+        assert np.abs(wp.to_rgba(p).astype(int) - ref["rgba"][y, x].astype(int)).max() <= 1
+    assert tracer.refractive_nodes >= len(n2) + len(n3) and tracer.total_internal > 0
 
 
 def test_ray_marched_pixels_of_the_sdf_scene(pkg, orc):

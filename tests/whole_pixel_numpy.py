@@ -95,7 +95,8 @@ def plane_intersect(o, ro, rd):    # src/utils/plane.rs:41-74
 
 class Whitted:
     """RayTracing::{albedo, color, light, trace_ray} (src/ray_tracing/ray_tracing.rs:17-78,160-241) for scenes of spheres and
-    planes with untextured Reflective materials (what src/bin/scene3.rs builds)."""
+    planes with untextured Reflective materials (what src/bin/scene3.rs builds) and Refractive ones (Fresnel weight,
+    refraction and reflection children, total internal reflection)."""
 
     def __init__(self, pkg, desc):
         self.pkg, self.d = pkg, desc
@@ -149,7 +150,57 @@ class Whitted:
                     l_acc = l_acc * F(0.5)
         return powf3(l_acc, 0.4166)
 
-    def color(self, ro, rd, depth, light_color, contribution):   # ray_tracing.rs:160-241, Reflective arm
+    def fresnel(self, incident, normal, refraction_index, reflectivity):   # Material::fresnel, src/objects.rs:178-205
+        n2, n1 = F(refraction_index), F(1.0)
+        r0 = (n1 - n2) / (n1 + n2)
+        r0 = r0 * r0
+        cos_x = dot(normal, -incident)
+        if n1 > n2:
+            n = n1 / n2
+            sin_t2 = n * n * (F(1.0) - cos_x * cos_x)
+            if sin_t2 > 1.0:
+                self.total_internal += 1
+                return F(1.0)
+            cos_x = np.sqrt(F(1.0) - sin_t2, dtype=np.float32)
+        x = F(1.0) - cos_x
+        ret = r0 + (F(1.0) - r0) * x * x * x * x * x
+        return F(reflectivity) + (F(1.0) - F(reflectivity)) * ret
+
+    def refraction_ray(self, rd, point, hit_normal, refraction_index):   # Ray::refraction_ray, src/ray.rs:138-165
+        normal = hit_normal
+        eta_t, eta_i = F(refraction_index), F(1.0)
+        c1 = dot(rd, hit_normal)
+        if c1 < 0:
+            c1 = -c1
+        else:
+            normal = -normal
+            eta_i, eta_t = eta_t, F(1.0)
+        eta = eta_i / eta_t
+        k = F(1.0) - eta * eta * (F(1.0) - c1 * c1)
+        if k < 0:
+            return None
+        c2 = np.sqrt(k, dtype=np.float32)
+        direction = eta * rd + normal * (eta * c1 - c2)
+        return point - EPSILON * normal, direction
+
+    def color_refractive(self, ro, rd, depth, light_color, contribution, hit, obj_index, m):   # ray_tracing.rs:197-236
+        _, point, normal = hit
+        albedo = v3(*m.albedo[:])
+        self.refractive_nodes += 1
+        refraction_color = v3(0, 0, 0)
+        kr = self.fresnel(rd, normal, m.refraction_index, m.reflectivity)
+        rr = self.refraction_ray(rd, point, normal, m.refraction_index)
+        if rr is not None:
+            refraction_color = self.color(rr[0], rr[1], depth + 1, light_color, contribution * albedo)
+        p_light = self.light(rd, hit, albedo, m, obj_index)
+        reflection_color = self.color(point + EPSILON * normal, reflect(rd, normal), depth + 1, p_light, contribution * albedo)
+        color = reflection_color * kr + refraction_color * (F(1.0) - kr) * F(m.transparency)
+        return color * albedo
+
+    total_internal = 0
+    refractive_nodes = 0
+
+    def color(self, ro, rd, depth, light_color, contribution):   # ray_tracing.rs:160-241
         if depth >= self.d.max_ray_bounces:
             return light_color
         h = self.trace_ray(ro, rd)
@@ -157,6 +208,8 @@ class Whitted:
             return light_color + v3(*self.d.ambient_color[:]) * contribution
         hit, obj_index = h
         m = self.materials[self.objects[obj_index].material_index]
+        if m.kind == self.pkg.RT_REFRACTIVE:
+            return self.color_refractive(ro, rd, depth, light_color, contribution, hit, obj_index, m)
         assert m.kind == self.pkg.RT_REFLECTIVE and m.texture < 0
         albedo = v3(*m.albedo[:])
         p_light = self.light(rd, hit, albedo, m, obj_index)
