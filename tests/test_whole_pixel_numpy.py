@@ -2,7 +2,7 @@
 
 The reference holds no vectors to pin the oracle with, so a second restatement of the per-pixel function, written from
 the Rust sources in another language and style, stands in: camera ray, closest hit, both shadow rays, Blinn-Phong, gamma,
-the reflection chain (scene3), the Refractive arm with Fresnel weight, refraction ray and total internal reflection (a scene
+the reflection chain (scene3), all six primitives' intersect() with their UVs and textures (scene1), the Refractive arm with Fresnel weight, refraction ray and total internal reflection (a scene
 with two glass spheres), and march, normal, occlusion, tri-planar texture, fade (scene4).  Agreement is to the
 accuracy of the transcendental functions (numpy's powf here, a specified algorithm in the oracle): 2e-5 absolute on the
 linear value, one step on the bytes.  PARITY UNPINNED against reference outputs all the same.
@@ -86,6 +86,40 @@ def test_whitted_pixels_through_glass(pkg, orc):
         assert np.allclose(p, lin[y, x, :3], rtol=5e-5, atol=3e-5), f"pixel ({x}, {y}): numpy {p}, oracle {lin[y, x, :3]}"
         assert np.abs(wp.to_rgba(p).astype(int) - ref["rgba"][y, x].astype(int)).max() <= 1
     assert tracer.refractive_nodes >= len(n2) + len(n3) and tracer.total_internal > 0
+
+
+def test_whitted_pixels_of_the_all_primitives_scene(pkg, orc):
+    """src/bin/scene1.rs: every primitive kind (sphere, bounded plane, cuboid, cone, cylinder, triangle), textured materials
+    with the primitives' own UVs (atan-derived on the sphere, cylinder and cone), a glass sphere: every intersect() of the
+    reference re-derived in numpy and checked against the oracle on camera pixels of every object, reflections included."""
+    s = pkg.Scene("scene1")
+    s.desc.max_ray_bounces = 3
+    w, h = 160, 120
+    cam = s.camera(w, h)
+    tex = s.textures()
+    ref = orc.render(s.desc, cam, tex, n_threads=4, want_linear=True)
+    lin = ref["linear"]
+    tracer = wp.Whitted(pkg, s.desc, tex)
+    rng = np.random.default_rng(5)
+    # sample until the camera rays have met every object of the scene at least twice
+    seen, pixels = {}, []
+    for _ in range(6000):
+        x, y = int(rng.integers(0, w)), int(rng.integers(0, h))
+        hit = tracer.trace_ray(*wp.camera_ray(cam, x, y))
+        key = -1 if hit is None else hit[1]
+        if seen.get(key, 0) < 4:
+            seen[key] = seen.get(key, 0) + 1
+            pixels.append((x, y))
+    assert len([k for k in seen if k >= 0]) == s.desc.n_objects, f"objects seen: {sorted(seen)}"
+    flips = 0
+    for x, y in pixels:
+        p = tracer.pixel(cam, x, y)
+        if not np.allclose(p, lin[y, x, :3], rtol=5e-5, atol=3e-5):
+            # numpy's atan against the specified atanf: a UV within an ulp of a texel border may pick the neighbouring texel
+            flips += 1
+            assert flips <= 2, f"pixel ({x}, {y}): numpy {p}, oracle {lin[y, x, :3]}"
+    assert tracer.kinds_hit >= {pkg.RT_SPHERE, pkg.RT_PLANE, pkg.RT_CUBOID, pkg.RT_CONE, pkg.RT_CYLINDER, pkg.RT_TRIANGLE}
+    assert tracer.textured_hits > 10 and tracer.refractive_nodes > 0
 
 
 def test_ray_marched_pixels_of_the_sdf_scene(pkg, orc):

@@ -63,7 +63,38 @@ def camera_ray(cam, x, y):
 # ---------------------------------------------------------------------------------------------------------------------
 # intersect() of the two kinds the Whitted test scene uses
 # ---------------------------------------------------------------------------------------------------------------------
-def sphere_intersect(o, ro, rd):   # src/utils/sphere.rs:98-147 -> (t, point, normal) or None
+INV_PI = F(1.0) / F(np.pi)     # src/utils/sphere.rs:13
+
+
+def atan(x):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.arctan(F(x), dtype=np.float32)
+
+
+def fdiv(a, b):                # f32 division with IEEE results for a zero divisor
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.divide(F(a), F(b), dtype=np.float32)
+
+
+def cross(a, b):               # glam Vec3::cross
+    return v3(a[1] * b[2] - b[1] * a[2], a[2] * b[0] - b[2] * a[0], a[0] * b[1] - b[0] * a[1])
+
+
+def signum(x):                 # f32::signum: +-1 by the sign bit, NaN stays NaN
+    if np.isnan(x):
+        return F(x)
+    return F(-1.0) if np.signbit(x) else F(1.0)
+
+
+def fmax(a, b):                # f32::max
+    return F(np.fmax(F(a), F(b)))
+
+
+def fmin(a, b):
+    return F(np.fmin(F(a), F(b)))
+
+
+def sphere_intersect(o, ro, rd):   # src/utils/sphere.rs:98-147 -> (t, point, normal, u, v) or None
     d = mat_mul_vec4(o.inv_transform[:], rd[0], rd[1], rd[2], 0.0)[:3]
     p = mat_mul_vec4(o.inv_transform[:], ro[0], ro[1], ro[2], 1.0)[:3]
     a = dot(d, d)
@@ -75,7 +106,9 @@ def sphere_intersect(o, ro, rd):   # src/utils/sphere.rs:98-147 -> (t, point, no
     t1 = (-b - np.sqrt(disc, dtype=np.float32)) / (F(2.0) * a)
     l = p + d * t1
     normal = normalize(mat_mul_vec4(o.transform[:], l[0], l[1], l[2], 0.0)[:3])
-    return t1, ro + rd * t1, normal
+    u = atan(fdiv(F(l[0] * l[0]) + F(l[1] * l[1]), l[2]))
+    v = atan(fdiv(l[1], l[0]))
+    return t1, ro + rd * t1, normal, v * INV_PI, u * INV_PI
 
 
 def plane_intersect(o, ro, rd):    # src/utils/plane.rs:41-74
@@ -90,7 +123,111 @@ def plane_intersect(o, ro, rd):    # src/utils/plane.rs:41-74
     if o.has_max_dist and (abs(hp[2]) > F(o.max_dist[1]) or abs(hp[0]) > F(o.max_dist[0])):
         return None
     sign = F(1.0) if dot(rd, n) < 0 else F(-1.0)
-    return t, hp, sign * n
+    return t, hp, sign * n, hp[0] * F(0.1), hp[2] * F(0.1)
+
+
+def local_ray(o, ro, rd):
+    return (mat_mul_vec4(o.inv_transform[:], ro[0], ro[1], ro[2], 1.0)[:3], mat_mul_vec4(o.inv_transform[:], rd[0], rd[1], rd[2], 0.0)[:3])
+
+
+def cuboid_intersect(o, ro, rd):   # src/utils/cuboid.rs:84-127
+    lo, ld = local_ray(o, ro, rd)
+    dim = v3(*o.dimension[:])
+    b_min = ((v3(dim[0], 0, 0) * F(-1.0) + v3(0, dim[1], 0) * F(-1.0)) + v3(0, 0, dim[2]) * F(-1.0)) + v3(0, 0, 0) * F(0.0)   # :47-48
+    b_max = ((v3(dim[0], 0, 0) * F(1.0) + v3(0, dim[1], 0) * F(1.0)) + v3(0, 0, dim[2]) * F(1.0)) + v3(0, 0, 0) * F(0.0)
+    inv = np.array([fdiv(1.0, ld[i]) for i in range(3)], dtype=np.float32)
+    with np.errstate(invalid="ignore"):
+        t_min = (b_min - lo) * inv
+        t_max = (b_max - lo) * inv
+    t_enter = np.array([fmin(t_min[i], t_max[i]) for i in range(3)], dtype=np.float32)
+    t_exit = np.array([fmax(t_min[i], t_max[i]) for i in range(3)], dtype=np.float32)
+    t_near = fmax(fmax(t_enter[0], t_enter[1]), t_enter[2])
+    t_far = fmin(fmin(t_exit[0], t_exit[1]), t_exit[2])
+    if t_near > t_far or t_far < 0:
+        return None
+    step = np.array([F(0.0) if t_enter[i] < t_near else F(1.0) for i in range(3)], dtype=np.float32)   # geometry.rs:21-27
+    a = -np.array([signum(ld[i]) for i in range(3)], dtype=np.float32) * step
+    normal = mat_mul_vec4(o.transform[:], a[0], a[1], a[2], 0.0)[:3]
+    hp = ro + rd * t_near
+    op = mat_mul_vec4(o.inv_transform[:], hp[0], hp[1], hp[2], 1.0)[:3]
+    ax, ay, az = abs(a[0]), abs(a[1]), abs(a[2])
+    u = (ax * op[1] + ay * op[2]) + az * op[0]
+    v = (ax * op[2] + ay * op[0]) + az * op[1]
+    return t_near, hp, normal, u, v
+
+
+def cylinder_intersect(o, ro, rd):   # src/utils/cylinder.rs:89-174
+    ro3, rd3 = local_ray(o, ro, rd)
+    a = F(rd3[0] * rd3[0]) + F(rd3[1] * rd3[1])
+    b = F(2.0) * (F(ro3[0] * rd3[0]) + F(ro3[1] * rd3[1]))
+    c = (F(ro3[0] * ro3[0]) + F(ro3[1] * ro3[1])) - F(1.0)
+    disc = b * b - F(4.0) * a * c
+    if disc > 0:
+        t1 = fdiv(-b - np.sqrt(disc, dtype=np.float32), F(2.0) * a)
+        h = ro3 + rd3 * t1
+        if abs(h[2]) < 0.5:
+            normal = normalize(mat_mul_vec4(o.transform[:], h[0], h[1], 0.0, 0.0)[:3])
+            return t1, ro + rd * t1, normal, atan(fdiv(h[1], h[0])), h[2] * F(2.0)
+    inv_z = fdiv(-1.0, rd3[2])
+    t1 = (ro3[2] - F(0.5)) * inv_z
+    t2 = (ro3[2] + F(0.5)) * inv_z
+    with np.errstate(invalid="ignore"):
+        h1, h2 = ro3 + rd3 * t1, ro3 + rd3 * t2
+    ok1 = (F(h1[0] * h1[0]) + F(h1[1] * h1[1])) < 1
+    ok2 = (F(h2[0] * h2[0]) + F(h2[1] * h2[1])) < 1
+    if ok1 and ok2:
+        t = t1 if t1 < t2 else t2
+    elif ok1:
+        t = t1
+    elif ok2:
+        t = t2
+    else:
+        return None
+    h = ro3 + rd3 * t
+    normal = normalize(mat_mul_vec4(o.transform[:], 0.0, 0.0, h[2], 0.0)[:3])
+    return t, ro + rd * t, normal, h[0], h[1]
+
+
+def cone_intersect(o, ro, rd):       # src/utils/cone.rs:72-152
+    ro3, rd3 = local_ray(o, ro, rd)
+    a = (F(rd3[0] * rd3[0]) + F(rd3[1] * rd3[1])) - rd3[2] * rd3[2]
+    b = F(2.0) * ((F(ro3[0] * rd3[0]) + F(ro3[1] * rd3[1])) - ro3[2] * rd3[2])
+    c = (F(ro3[0] * ro3[0]) + F(ro3[1] * ro3[1])) - ro3[2] * ro3[2]
+    disc = b * b - F(4.0) * a * c
+    cone = None
+    if disc > 0:
+        t1 = fdiv(-b - np.sqrt(disc, dtype=np.float32), F(2.0) * a)
+        h = ro3 + rd3 * t1
+        if h[2] > 0 and h[2] < 1:
+            n = v3(h[0], h[1], -np.sqrt(F(h[0] * h[0]) + F(h[1] * h[1]), dtype=np.float32))
+            normal = normalize(mat_mul_vec4(o.transform[:], n[0], n[1], n[2], 0.0)[:3])
+            cone = (t1, ro + rd * t1, normal, atan(fdiv(h[1], h[0])), h[2] * F(2.0) + F(1.0))
+    t1 = fdiv(ro3[2] - F(1.0), -rd3[2])
+    with np.errstate(invalid="ignore"):
+        h1 = ro3 + rd3 * t1
+    if (F(h1[0] * h1[0]) + F(h1[1] * h1[1])) < 1:
+        if cone is not None and cone[0] < t1:
+            return cone
+        normal = mat_mul_vec4(o.transform[:], 0.0, 0.0, 1.0, 0.0)[:3]
+        return t1, ro + rd * t1, normal, h1[0], h1[1]
+    return cone
+
+
+def triangle_intersect(o, ro, rd):   # src/utils/triangle.rs:35-88
+    p1, p2, p3 = v3(*o.v1[:]), v3(*o.v2[:]), v3(*o.v3[:])
+    edge_ab, edge_ac = p2 - p1, p3 - p1
+    normal = cross(edge_ab, edge_ac)
+    denom = dot(rd, normal)
+    if abs(denom) < 1e-6:
+        return None
+    t = dot(p1 - ro, normal) / denom
+    hp = ro + rd * t
+    edge_bc, edge_ca = p3 - p2, p1 - p3
+    a_test, b_test, c_test = cross(edge_ab, hp - p1), cross(edge_bc, hp - p2), cross(edge_ca, hp - p3)
+    if not (dot(a_test, normal) > 0 and dot(b_test, normal) > 0 and dot(c_test, normal) > 0):
+        return None
+    sign = -signum(dot(rd, normal))
+    return t, hp, normalize(sign * normal), dot(cross(edge_ab, hp - p1), normal), dot(cross(edge_ca, hp - p3), normal)
 
 
 class Whitted:
@@ -98,23 +235,23 @@ class Whitted:
     planes with untextured Reflective materials (what src/bin/scene3.rs builds) and Refractive ones (Fresnel weight,
     refraction and reflection children, total internal reflection)."""
 
-    def __init__(self, pkg, desc):
-        self.pkg, self.d = pkg, desc
+    def __init__(self, pkg, desc, textures=()):
+        self.pkg, self.d, self.tex = pkg, desc, textures
         self.objects = [desc.objects[i] for i in range(desc.n_objects)]
         self.materials = [desc.materials[i] for i in range(desc.n_materials)]
         self.lights = [desc.lights[i] for i in range(desc.n_lights)]
         self.rays = 0
+        self.textured_hits = 0
+        self.kinds_hit = set()
 
     def trace_ray(self, ro, rd):
         self.rays += 1
         closest, best = F32_MAX, None
         for idx, o in enumerate(self.objects):
-            if o.kind == self.pkg.RT_SPHERE:
-                h = sphere_intersect(o, ro, rd)
-            elif o.kind == self.pkg.RT_PLANE:
-                h = plane_intersect(o, ro, rd)
-            else:
-                raise NotImplementedError
+            P = self.pkg                # Ray::hit, src/ray.rs:167-177
+            fn = {P.RT_SPHERE: sphere_intersect, P.RT_PLANE: plane_intersect, P.RT_CUBOID: cuboid_intersect, P.RT_CYLINDER: cylinder_intersect,
+                  P.RT_CONE: cone_intersect, P.RT_TRIANGLE: triangle_intersect}.get(o.kind)
+            h = fn(o, ro, rd) if fn else None
             if h is not None and h[0] > 0 and h[0] < closest:
                 closest, best = h[0], (h, idx)
         return best
@@ -136,7 +273,7 @@ class Whitted:
         return ambience + diffuse + specular
 
     def light(self, rd, hit, albedo, m, obj_index):   # ray_tracing.rs:28-57
-        _, point, normal = hit
+        point, normal = hit[1], hit[2]
         l_acc = v3(0, 0, 0)
         for l in self.lights:
             k = self.blinn_phong(rd, point, normal, l, albedo, m)
@@ -184,7 +321,7 @@ class Whitted:
         return point - EPSILON * normal, direction
 
     def color_refractive(self, ro, rd, depth, light_color, contribution, hit, obj_index, m):   # ray_tracing.rs:197-236
-        _, point, normal = hit
+        point, normal = hit[1], hit[2]
         albedo = v3(*m.albedo[:])
         self.refractive_nodes += 1
         refraction_color = v3(0, 0, 0)
@@ -207,13 +344,17 @@ class Whitted:
         if h is None:
             return light_color + v3(*self.d.ambient_color[:]) * contribution
         hit, obj_index = h
+        self.kinds_hit.add(int(self.objects[obj_index].kind))
         m = self.materials[self.objects[obj_index].material_index]
         if m.kind == self.pkg.RT_REFRACTIVE:
             return self.color_refractive(ro, rd, depth, light_color, contribution, hit, obj_index, m)
-        assert m.kind == self.pkg.RT_REFLECTIVE and m.texture < 0
+        assert m.kind == self.pkg.RT_REFLECTIVE
         albedo = v3(*m.albedo[:])
+        if m.texture >= 0:             # ray_tracing.rs:177-179
+            self.textured_hits += 1
+            albedo = from_uv(self.tex[m.texture], hit[3], hit[4])
         p_light = self.light(rd, hit, albedo, m, obj_index)
-        _, point, normal = hit
+        point, normal = hit[1], hit[2]
         rdir = normalize(reflect(rd, normal + v3(0, 0, 0)))        # src/ray.rs:101-122, no jitter
         reflected = self.color(point + normal * EPSILON, rdir, depth + 1, p_light, contribution * albedo)
         rough = F(m.roughness)
