@@ -328,12 +328,13 @@ typedef struct rt_hierarchy_info {
 } rt_hierarchy_info;
 int32_t rt_get_hierarchy_info(rt_ctx *ctx, rt_hierarchy_info *out);
 
-/* Self-check of the two transcendental functions the kernels share with every caller that wants bit-equal frames:
+/* Self-check of the transcendental functions the kernels share with every caller that wants bit-equal frames, and of
+ * their square root (op RT_MATH_SQRT: out[i] = f32::sqrt(x[i]) as the kernels evaluate it, correctly rounded; y ignored):
  * op RT_MATH_POWF: out[i] = powf(x[i], y[i]) as Ray::blinn_phong and the gamma steps evaluate it (f32::powf at src/ray.rs:81,
  * src/ray_tracing/ray_tracing.rs:55, src/ray_marching/ray_marching.rs:178); op RT_MATH_ATANF: out[i] = atanf(x[i]) (f32::atan at
  * src/utils/sphere.rs:136-137; y is ignored and may be NULL).  Evaluated on the device by the same inlined code the
  * render kernels use; host pointers, n elements each.  Synchronous. */
-enum rt_math_op { RT_MATH_POWF = 0, RT_MATH_ATANF = 1 };
+enum rt_math_op { RT_MATH_POWF = 0, RT_MATH_ATANF = 1, RT_MATH_SQRT = 2 };
 int32_t rt_eval_math(rt_ctx *ctx, int32_t op, size_t n, const float *x, const float *y, float *out);
 
 /* Waits for the context's stream and sums the per-workgroup counters of the last render. */

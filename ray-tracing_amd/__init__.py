@@ -30,7 +30,7 @@ REPO_ROOT = os.path.dirname(_HERE)
 RT_SPHERE, RT_TRIANGLE, RT_CUBOID, RT_PLANE, RT_CYLINDER, RT_CONE, RT_UNION, RT_SUBSTRACTION = range(8)
 RT_REFLECTIVE, RT_REFRACTIVE = 0, 1
 RT_DIRECTIONAL, RT_POSITIONAL, RT_SPHERICAL_POSITIONAL = 0, 1, 2
-RT_MATH_POWF, RT_MATH_ATANF = 0, 1
+RT_MATH_POWF, RT_MATH_ATANF, RT_MATH_SQRT = 0, 1, 2
 RT_RENDER_ONE_LANE_PER_PIXEL, RT_RENDER_SKIP_ACCUM_STORE, RT_RENDER_SAMPLE_SHARES = 1, 2, 4
 
 COUNTER_NAMES = [
@@ -444,7 +444,7 @@ class Context:
         return {k: int(getattr(h, k)) for k, _ in rt_hierarchy_info._fields_ if k != "reserved"}
 
     def eval_math(self, op: int, x: np.ndarray, y: np.ndarray = None) -> np.ndarray:
-        """rt_eval_math: the kernels' powf(x, y) (op RT_MATH_POWF) or atanf(x) (op RT_MATH_ATANF), evaluated on the device."""
+        """rt_eval_math: the kernels' powf(x, y) (op RT_MATH_POWF), atanf(x) (op RT_MATH_ATANF) or sqrt(x) (op RT_MATH_SQRT), evaluated on the device."""
         x = np.ascontiguousarray(x, dtype=np.float32).ravel()
         if y is not None:
             y = np.ascontiguousarray(y, dtype=np.float32).ravel()

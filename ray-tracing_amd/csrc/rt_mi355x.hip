@@ -944,19 +944,19 @@ int32_t rt_read_ray_directions(rt_ctx *c, float *out, size_t n_vec3) {
     RT_GUARD_END(c)
 }
 
-// One lane per element; the same inlined rt_powf / rt_atanf as the render kernels, tables staged in LDS the same way.
+// One lane per element; the same inlined rt_powf / rt_atanf / rt_sqrt as the render kernels, tables staged in LDS the same way.
 __global__ void __launch_bounds__(256) rt_math_kernel(int op, size_t n, const float *x, const float *y, float *out) {
     __shared__ __attribute__((aligned(16))) double s_pow[RT_POW_LDS_DOUBLES];
     rt_pow_lds_init(s_pow);
     __syncthreads();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = op == RT_MATH_POWF ? rt_powf(x[i], y[i], s_pow) : rt_atanf(x[i]);
+        out[i] = op == RT_MATH_POWF ? rt_powf(x[i], y[i], s_pow) : (op == RT_MATH_ATANF ? rt_atanf(x[i]) : rt_sqrt(x[i]));
 }
 
 int32_t rt_eval_math(rt_ctx *c, int32_t op, size_t n, const float *x, const float *y, float *out) {
     RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
-    if (op != RT_MATH_POWF && op != RT_MATH_ATANF) return fail(c, RT_ERR_INVALID_ARGUMENT, "unknown math op");
+    if (op != RT_MATH_POWF && op != RT_MATH_ATANF && op != RT_MATH_SQRT) return fail(c, RT_ERR_INVALID_ARGUMENT, "unknown math op");
     if (n == 0) return RT_OK;
     if (!x || !out || (op == RT_MATH_POWF && !y)) return fail(c, RT_ERR_INVALID_ARGUMENT, "null operand array");
     RT_HIP(c, hipSetDevice(c->device));

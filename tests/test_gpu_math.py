@@ -96,3 +96,24 @@ def test_eval_math_rejects_bad_arguments(pkg, ctx):
     with pytest.raises(Exception):
         ctx.eval_math(7, np.ones(4, np.float32), np.ones(4, np.float32))
     assert ctx.eval_math(pkg.RT_MATH_POWF, np.zeros(0, np.float32), np.zeros(0, np.float32)).size == 0
+
+
+def test_sqrt_on_every_positive_number_and_the_special_cases(pkg, ctx):
+    """The kernels' square root (a short expansion when a whole wavefront holds positive normal numbers from 2^-96 on, the
+    compiler's full IEEE expansion otherwise) against the correctly rounded root, which is what f32::sqrt returns: all
+    2^31 non-negative bit patterns in order (wavefronts of the short form, of the full one, and the mixed ones at the range
+    borders), then shuffled samples that mix usual and unusual numbers inside every wavefront, negatives and NaNs included."""
+    chunk = 1 << 26
+    for start in range(0, 1 << 31, chunk):
+        x = np.arange(start, start + chunk, dtype=np.uint32).view(np.float32)
+        with np.errstate(invalid="ignore"):
+            want = np.sqrt(x)
+        assert_same_floats(ctx.eval_math(pkg.RT_MATH_SQRT, x), want, f"sqrt, bit patterns from {start:#x}")
+    rng = np.random.default_rng(17)
+    bits = rng.integers(0, 1 << 32, 1 << 22, dtype=np.uint64).astype(np.uint32)
+    mixed = np.concatenate([bits.view(np.float32), np.tile(SPECIAL, 4096), rng.uniform(0, 1e-28, 1 << 20).astype(np.float32),
+                            (10.0 ** rng.uniform(-30, 30, 1 << 21)).astype(np.float32)])
+    rng.shuffle(mixed)
+    with np.errstate(invalid="ignore"):
+        want = np.sqrt(mixed)
+    assert_same_floats(ctx.eval_math(pkg.RT_MATH_SQRT, mixed), want, "sqrt, mixed wavefronts")
