@@ -93,8 +93,13 @@ RT_DEV uint32_t rt_as_u32(float f) { if (!(f > 0.0f)) return 0u; if (f >= 429496
 typedef const double *PowTab;
 RT_DEV void rt_pow_lds_init(double *tab) {
 #if RT_POW_LDS
-    for (uint32_t i = threadIdx.x; i < (uint32_t)RT_POW_LDS_DOUBLES; i += blockDim.x)
-        tab[i] = i < 94u ? rt_pow_logtab[i] * ((i & 1u) ? 32.0 : 1.0) : __longlong_as_double((long long)rt_pow_exp2bits[i - 94u]);
+    // one load per staged entry (the address is selected, not the value: the two source tables cost one memory round trip)
+    for (uint32_t i = threadIdx.x; i < (uint32_t)RT_POW_LDS_DOUBLES; i += blockDim.x) {
+        const unsigned long long *src = i < 94u ? reinterpret_cast<const unsigned long long *>(rt_pow_logtab) + i
+                                                : reinterpret_cast<const unsigned long long *>(rt_pow_exp2bits) + (i - 94u);
+        const double v = __longlong_as_double((long long)*src);
+        tab[i] = (i < 94u && (i & 1u)) ? v * 32.0 : v;
+    }
 #else
     (void)tab;
 #endif

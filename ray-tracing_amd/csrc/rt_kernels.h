@@ -717,6 +717,11 @@ __global__ void __launch_bounds__(256, BVH ? 5 : (REFR ? RT_REFR_WAVES : 7)) rt_
     __shared__ uint32_t s_cnt[(EVENTS ? RT_CNT_COUNT : 0) + 1];
     __shared__ __attribute__((aligned(16))) double s_pow[RT_POW_LDS_DOUBLES];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    uint32_t px, py;
+    const bool in_frame = lane_pixel(C, F, px, py);
+    // Camera.ray_directions[pos] (src/renderer.rs:49), requested before the tables are staged: the two memory round trips
+    // of a wavefront's start overlap (lanes outside the frame take pixel 0's direction, which nobody uses)
+    const f3 rd_first = ld3(C.ray_dirs + 3u * (size_t)(in_frame ? py * C.width + px : 0u));
     for (uint32_t i = tid; i < (uint32_t)((EVENTS ? RT_CNT_COUNT : 0) + 1); i += nthr) s_cnt[i] = 0u;
     rt_pow_lds_init(s_pow);
     __syncthreads();
@@ -725,15 +730,12 @@ __global__ void __launch_bounds__(256, BVH ? 5 : (REFR ? RT_REFR_WAVES : 7)) rt_
     cnt.clear();
     DG_DECL
     DG_BEGIN(DG_TOTAL)
-    uint32_t px, py;
-    if (lane_pixel(C, F, px, py)) {
+    if (in_frame) {
         const uint32_t pos = py * C.width + px;
         cnt.add(RT_CNT_RAYGEN);
         cnt.add(RT_CNT_PIXEL_PACK);
         f3 ro = ld3(C.position);
-        DG_BEGIN(DG_RAYGEN)
-        f3 rd = ld3(C.ray_dirs + 3u * (size_t)pos);  // Camera.ray_directions[pos] (src/renderer.rs:49)
-        DG_END(DG_RAYGEN)
+        f3 rd = rd_first;
         f3 L = splat3(0.0f);      // light_color carried down
         f3 Cc = splat3(1.0f);     // contribution carried down
         f3 V = splat3(0.0f);      // value returned by the subtree just finished
