@@ -91,6 +91,8 @@ def main() -> None:
                     help="default workload only: without the ride-along measurement of the 8K / 10 000-sphere / 64-spp frame")
     ap.add_argument("--keep-accum-store", action="store_true",
                     help="non-accumulating workloads: also write the frame's linear value to the accumulator (default: RT_RENDER_SKIP_ACCUM_STORE)")
+    ap.add_argument("--no-sky-tiles", action="store_true",
+                    help="small scenes: render without the per-tile classification that lets workgroups of sky end without tracing (RT_RENDER_NO_SKY_TILES)")
     args = ap.parse_args()
     with_config5 = args.workload is None and not args.no_config5 and args.shard in (None, "samples")
     if args.workload is None:
@@ -174,7 +176,7 @@ def main() -> None:
         def render(sample_index: int, acc: bool = accumulate, rows=rows_arg, events: bool = False) -> None:
             # the timed region is bracketed by this script's own events, so the library's per-launch timing events are off
             ctx.render_device(frame_index=sample_index if acc else 1, accumulate=acc, seed=0x5EED,
-                              flags=pkg.RT_RENDER_SKIP_ACCUM_STORE if (skip_store and not acc) else 0,
+                              flags=(pkg.RT_RENDER_SKIP_ACCUM_STORE if (skip_store and not acc) else 0) | (pkg.RT_RENDER_NO_SKY_TILES if args.no_sky_tiles else 0),
                               rows=(rows[0], rows[1]) if rows else None, tile_row_stride=rows[2] if rows else 0,
                               d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh, no_timing=not events, collect_events=events)
 
@@ -298,6 +300,14 @@ def main() -> None:
             achieved = flops / (kernel_ms * 1e-3) / 1e12
             value = rays_per_step_all * steps / elapsed_max / 1e6
             traffic, traffic_note = measured_traffic(workload, pkg.LIB_PATH)
+            hinfo = ctx.hierarchy_info()
+            if args.no_sky_tiles:
+                sky_tiles = "off (--no-sky-tiles)"
+            elif hinfo["classified_workgroups"]:
+                sky_tiles = (f"{hinfo['sky_workgroups']} of {hinfo['classified_workgroups']} workgroups hold only tiles that no camera ray leaves towards an object; "
+                             "they write the value of a miss without tracing (classified when scene, camera or rows change: here once, before the timed steps)")
+            else:
+                sky_tiles = "not used by this workload's kernel"
             out = {
                 "metric": "Mrays/sec (primary+secondary) and frame ms at 4K",
                 "value": round(value, 2),
@@ -315,6 +325,7 @@ def main() -> None:
                            "max_ray_bounces": int(scene.desc.max_ray_bounces), "samples_per_step": spp,
                            "rays_per_step_per_rank": int(rays_rank), "sharding": shard, "clock_prewarm_ms": int(CLOCK_PREWARM_S * 1e3),
                            "accumulator_store": "n/a (accumulating)" if accumulate or shard == "samples" else ("skipped" if skip_store else "written"),
+                           "sky_tiles": sky_tiles,
                            "ranks": world, "backend": backend if use_dist else "none", "exchange_ms_per_step": round(exchange_ms, 4),
                            "collective": ("none" if shard in ("none", "frames") or not xch.collectives else
                                           "all_gather(rgba8 tile rows)" if shard == "rows" else

@@ -230,7 +230,12 @@ typedef enum rt_render_flag {
     RT_RENDER_SKIP_ACCUM_STORE = 2,
     /* rt_render_samples_device deals the tile rows to interleaved shares on streams of its own only for frames large enough
      * to gain from it; this flag makes it do so whatever the frame size (tests of that path on small frames). */
-    RT_RENDER_SAMPLE_SHARES = 4
+    RT_RENDER_SAMPLE_SHARES = 4,
+    /* Small scenes (linear scan) are rendered with a per-tile classification in front: 8x8-pixel tiles whose camera rays cannot
+     * reach any object (by the objects' bounding spheres against the tile's pyramid of rays) get the value of a miss without
+     * being traced.  The classification is recomputed whenever the scene, the camera or the rows of the launch change.  This flag
+     * renders without it (A/B runs and tests that compare the two). */
+    RT_RENDER_NO_SKY_TILES = 8
 } rt_render_flag;
 
 /* Creates a context bound to HIP device `device_id` (one context per GPU; one process per GPU
@@ -324,7 +329,9 @@ typedef struct rt_hierarchy_info {
     uint32_t two_child_nodes;    /* nodes of the quantised two-child hierarchy; 0 unless the scene is diffuse without glass */
     uint32_t two_child_linear;   /* objects outside it: planes and objects too large for its 16-bit grid                   */
     uint32_t regrouping_kernel;  /* 1: rt_render_device traces this scene with the kernel that re-groups rays between bounces */
-    uint32_t reserved[3];
+    uint32_t sky_workgroups;     /* last tile classification (see RT_RENDER_NO_SKY_TILES): workgroups whose tiles are all sky ... */
+    uint32_t classified_workgroups; /* ... of this many workgroups of that launch; both 0 when no launch has used one          */
+    uint32_t reserved[1];
 } rt_hierarchy_info;
 int32_t rt_get_hierarchy_info(rt_ctx *ctx, rt_hierarchy_info *out);
 

@@ -31,7 +31,7 @@ RT_SPHERE, RT_TRIANGLE, RT_CUBOID, RT_PLANE, RT_CYLINDER, RT_CONE, RT_UNION, RT_
 RT_REFLECTIVE, RT_REFRACTIVE = 0, 1
 RT_DIRECTIONAL, RT_POSITIONAL, RT_SPHERICAL_POSITIONAL = 0, 1, 2
 RT_MATH_POWF, RT_MATH_ATANF, RT_MATH_SQRT = 0, 1, 2
-RT_RENDER_ONE_LANE_PER_PIXEL, RT_RENDER_SKIP_ACCUM_STORE, RT_RENDER_SAMPLE_SHARES = 1, 2, 4
+RT_RENDER_ONE_LANE_PER_PIXEL, RT_RENDER_SKIP_ACCUM_STORE, RT_RENDER_SAMPLE_SHARES, RT_RENDER_NO_SKY_TILES = 1, 2, 4, 8
 
 COUNTER_NAMES = [
     "rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "rays_march", "raygen",
@@ -120,7 +120,8 @@ class rt_stats(C.Structure):
 
 class rt_hierarchy_info(C.Structure):
     _fields_ = [("stackless_nodes", C.c_uint32), ("stackless_linear", C.c_uint32), ("two_child_nodes", C.c_uint32),
-                ("two_child_linear", C.c_uint32), ("regrouping_kernel", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("two_child_linear", C.c_uint32), ("regrouping_kernel", C.c_uint32), ("sky_workgroups", C.c_uint32),
+                ("classified_workgroups", C.c_uint32), ("reserved", C.c_uint32 * 1)]
 
 
 class rt_render_params(C.Structure):

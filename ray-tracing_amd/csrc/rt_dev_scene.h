@@ -126,4 +126,7 @@ struct DevFrame {
     float *accum;        // width*height float4
     uint32_t *counters;  // [gridDim.x][n_counters]
     unsigned long long *diag;  // diagnostic builds only (RT_DIAG): per-section wave-cycle sums
+    // rt_trace_kernel, or null: one word per workgroup of this launch, byte k = 1 when no camera ray of wavefront k's tile can
+    // reach any object (rt_tile_sky_kernel); such tiles get the value of a miss without reading their directions
+    const uint32_t *tile_sky;
 };

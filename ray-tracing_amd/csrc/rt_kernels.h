@@ -719,6 +719,23 @@ __global__ void __launch_bounds__(256, BVH ? 5 : (REFR ? RT_REFR_WAVES : 7)) rt_
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     uint32_t px, py;
     const bool in_frame = lane_pixel(C, F, px, py);
+    // Sky tiles (rt_tile_sky_kernel): a workgroup of nothing else writes the value of a miss (ray_tracing.rs:238-240) and ends
+    // -- no directions, no tables, no barrier.  (A sky tile inside a mixed workgroup takes the ordinary path: skipping it there
+    // measured slower, the wave-uniform flag lives through the whole kernel.)
+    // (not in the variants with refractive frames: they sit at their register budget, and the extra prologue cost the scene
+    // with glass 3 % while 3 % of its workgroups are sky)
+    constexpr bool kSkyTiles = !EVENTS && !BVH && !REFR;
+    uint32_t sky_word = 0u;
+    if (kSkyTiles && F.tile_sky) sky_word = F.tile_sky[rt_block_index()];
+    if (kSkyTiles && sky_word == (0x01010101u >> (8u * (4u - (nthr >> 6))))) {
+        if (in_frame) store_pixel(F, py * C.width + px, splat3(0.0f) + ld3(S.ambient) * splat3(1.0f));
+        if (tid == 0u) {   // one primary ray per pixel of the workgroup's tiles that lies inside the frame (see lane_pixel)
+            const uint32_t x0 = blockIdx.x * (nthr >> 6) * 8u, y0 = F.row_begin + (gridDim.y - 1u - blockIdx.y) * F.tile_row_step;
+            const uint32_t x1 = x0 + (nthr >> 6) * 8u < C.width ? x0 + (nthr >> 6) * 8u : C.width, y1 = y0 + 8u < F.row_end ? y0 + 8u : F.row_end;
+            F.counters[rt_block_index()] = (x1 > x0 && y1 > y0) ? (x1 - x0) * (y1 - y0) : 0u;
+        }
+        return;
+    }
     // Camera.ray_directions[pos] (src/renderer.rs:49), requested before the tables are staged: the two memory round trips
     // of a wavefront's start overlap (lanes outside the frame take pixel 0's direction, which nobody uses)
     const f3 rd_first = ld3(C.ray_dirs + 3u * (size_t)(in_frame ? py * C.width + px : 0u));
@@ -1216,6 +1233,102 @@ __global__ void __launch_bounds__(256, 8) rt_march_kernel(const DevScene S, cons
         store_pixel(F, pos, color);
     }
     flush_counters<EVENTS>(F, cnt, s_cnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sky tiles.  Not part of the reference: screen-space culling for rt_trace_kernel's linear-scan variants.  For every
+// workgroup of a render launch, one thread decides per wavefront tile (8x8 pixels) whether ANY camera ray of the tile can
+// reach ANY object; the render kernel gives the tiles that cannot the value of a miss without reading their directions.
+// The test is conservative: the tile's rays lie inside the pyramid through the pixel centres one pixel outside its corners
+// (directions are a projective image of the pixel grid, so the pyramid of a rectangle contains the rays of its interior);
+// an object is unreachable when its bounding sphere (DevObject::bs, the sphere of the scan's own rejection test, enlarged
+// once more here) lies outside one of the pyramid's four side planes, a plane when the sign of its denominator at all four
+// corners rules out a positive distance.  Objects without finite bounds count as reachable.  Which candidate tests run never
+// changes a pixel (see trace_closest); this only moves the decision from every ray to the tile.
+// ------------------------------------------------------------------------------------------------
+RT_DEV f3 camera_ray_at(const DevCamera &C, float fx, float fy) {   // camera_ray for a real-valued pixel position
+    float sx = 2.0f * (fx * C.inv_w) - 1.0f, sy = 2.0f * (fy * C.inv_h) - 1.0f;
+    float tx = ((C.ip_c0[0] * sx + C.ip_c1[0] * sy) + C.ip_c2[0]) + C.ip_c3[0];
+    float ty = ((C.ip_c0[1] * sx + C.ip_c1[1] * sy) + C.ip_c2[1]) + C.ip_c3[1];
+    float tz = ((C.ip_c0[2] * sx + C.ip_c1[2] * sy) + C.ip_c2[2]) + C.ip_c3[2];
+    float tw = ((C.ip_c0[3] * sx + C.ip_c1[3] * sy) + C.ip_c2[3]) + C.ip_c3[3];
+    f3 v = mk3(tx / tw, ty / tw, tz / tw);
+    f3 world = xf_dir(C.iv, v);
+    return normalize(world - ld3(C.position));
+}
+RT_DEV bool tile_is_sky(const DevScene &S, const DevCamera &C, uint32_t x0, uint32_t y0) {
+    const f3 ro = ld3(C.position);
+    const float xa = (float)x0 - 1.0f, xb = (float)x0 + 8.0f, ya = (float)y0 - 1.0f, yb = (float)y0 + 8.0f;
+    f3 d[4] = {camera_ray_at(C, xa, ya), camera_ray_at(C, xb, ya), camera_ray_at(C, xb, yb), camera_ray_at(C, xa, yb)};
+    const f3 dc = camera_ray_at(C, (float)x0 + 3.5f, (float)y0 + 3.5f);
+    f3 nrm[4];
+    bool usable = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        f3 n = cross(d[k], d[(k + 1) & 3]);
+        const float len = length(n);
+        if (!(len > 1e-12f)) usable = false;
+        n = n * (1.0f / len);
+        if (dot(n, dc) < 0.0f) n = -n;   // inward
+        nrm[k] = n;
+        if (!(dot(n, dc) > 0.0f)) usable = false;   // NaN or a degenerate pyramid
+    }
+    if (!usable) return false;
+    for (uint32_t i = 0; i < S.n_objects; i++) {
+        const DevObject &o = S.objects[i];
+        const int kind = o.kind;
+        if (kind == RT_UNION || kind == RT_SUBSTRACTION) continue;   // never hit by rays (src/ray.rs:175)
+        bool reach = true;
+        if (o.bounded) {
+            const f3 oc = ld3(o.bs) - ro;
+            const float radius = rt_sqrt(o.bs[3]) * 1.01f + 1e-4f * length(oc) + 1e-4f;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (dot(nrm[k], oc) < -radius) reach = false;
+        }
+        if (kind == RT_PLANE) {
+            const f3 pn = ld3(o.p);
+            const float num = dot(ld3(o.p + 3) - ro, pn);
+            const float eps = 1e-5f * length(pn);
+            bool behind = num != 0.0f, ahead = num != 0.0f;
+            f3 lo = splat3(RT_F32_MAX), hi = splat3(-RT_F32_MAX);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float denom = dot(d[k], pn);
+                behind = behind && (num > 0.0f ? denom < -eps : denom > eps);   // every corner: distance negative
+                ahead = ahead && (num > 0.0f ? denom > eps : denom < -eps);     // every corner: distance positive
+                const f3 hp = ro + d[k] * (num / denom);
+                lo = vmin(lo, hp); hi = vmax(hi, hp);
+            }
+            if (behind) reach = false;
+            // a plane with max_dist (src/utils/plane.rs:55-59): the tile's rays meet it inside the quadrilateral of the four
+            // corner hits; entirely beyond the limit in x or in z, every hit is rejected
+            if (ahead && o.p[8] != 0.0f) {
+                const float mx = o.p[6] * 1.001f + 1e-3f, mz = o.p[7] * 1.001f + 1e-3f;
+                if (lo.x > mx || hi.x < -mx || lo.z > mz || hi.z < -mz) reach = false;
+            }
+        } else if (!o.bounded) {
+            return false;
+        }
+        if (reach) return false;
+    }
+    return true;
+}
+// One thread per workgroup of a render launch with grid (grid_x, grid_y) and `waves` wavefronts per workgroup; the word's
+// byte k is wavefront k's tile (tiles outside the frame count as sky: they have no pixels).
+__global__ void __launch_bounds__(64) rt_tile_sky_kernel(const DevScene S, const DevCamera C, const DevFrame F, uint32_t grid_x, uint32_t grid_y, uint32_t waves,
+                                                          uint32_t *__restrict__ out) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= grid_x * grid_y) return;
+    const uint32_t by = idx / grid_x, bx = idx - by * grid_x;
+    const uint32_t y0 = F.row_begin + (grid_y - 1u - by) * F.tile_row_step;
+    uint32_t word = 0u;
+    for (uint32_t k = 0; k < waves; k++) {
+        const uint32_t x0 = (bx * waves + k) * 8u;
+        const bool sky = x0 >= C.width || y0 >= F.row_end || tile_is_sky(S, C, x0, y0);
+        word |= (sky ? 1u : 0u) << (8u * k);
+    }
+    out[idx] = word;
 }
 
 // ------------------------------------------------------------------------------------------------

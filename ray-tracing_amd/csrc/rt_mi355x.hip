@@ -106,6 +106,10 @@ struct rt_ctx {
     size_t n_bvh2_nodes = 0;      // nodes of the quantised two-child hierarchy of the current scene
     uint64_t wf_order_key = 0;    // frame / row range the tile-row costs in wf_ctrl belong to
     uint32_t scene_serial = 0;    // bumped by rt_set_scene, rt_update_objects and rt_set_camera
+    DevBuf<uint32_t> tile_sky;    // rt_tile_sky_kernel's word per workgroup of the launch described by tile_sky_key
+    uint64_t tile_sky_key[2] = {~0ull, ~0ull};
+    uint32_t tile_sky_words = 0, tile_sky_waves = 4;
+    hipStream_t tile_sky_stream = nullptr;   // stream of the launch that classified last
     DevBuf<uint32_t> counters;
     // rt_render_samples_device: the frame's tile rows are dealt to kBatchLanes interleaved shares, each with its own stream, pools,
     // work counter and ray counters, so that launches of different shares overlap (see the entry point)
@@ -646,6 +650,23 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
     F.accum = d_accum ? (float *)d_accum : c->accum.ptr;
     F.counters = counters;
     F.diag = nullptr;
+    F.tile_sky = nullptr;
+    // Sky tiles for the linear-scan trace kernels: classified once per (scene, camera, rows of the launch), on the launch's
+    // stream ahead of the first render that needs them; every later launch over the same rows reuses the words.
+    const bool sky_tiles = !regroup && !refill && !S.ray_marching && !S.bvh_nodes && !c->has_refractive && !events && !noalloc && !lane && maxd >= 1u &&
+                           S.n_objects >= 1u &&
+                           !(p->flags & RT_RENDER_NO_SKY_TILES);
+    if (sky_tiles) {
+        const uint64_t k0 = ((uint64_t)c->scene_serial << 32) | ((uint64_t)c->camera.width << 16) | (uint64_t)c->camera.height;
+        const uint64_t k1 = ((uint64_t)rb << 40) | ((uint64_t)re << 16) | ((uint64_t)stride << 4) | (uint64_t)waves_per_block;
+        if (k0 != c->tile_sky_key[0] || k1 != c->tile_sky_key[1] || c->tile_sky_words != blocks) {
+            RT_HIP(c, c->tile_sky.ensure(blocks));
+            hipLaunchKernelGGL(rt_tile_sky_kernel, dim3((blocks + 63u) / 64u), dim3(64), 0, s, S, c->camera, F, grid.x, grid.y, waves_per_block, c->tile_sky.ptr);
+            RT_HIP(c, hipGetLastError());
+            c->tile_sky_key[0] = k0; c->tile_sky_key[1] = k1; c->tile_sky_words = blocks; c->tile_sky_waves = waves_per_block; c->tile_sky_stream = s;
+        }
+        F.tile_sky = c->tile_sky.ptr;
+    }
 #ifdef RT_DIAG
     static unsigned long long *s_diag = nullptr;
     static size_t s_diag_cap = 0;
@@ -1024,6 +1045,15 @@ int32_t rt_get_hierarchy_info(rt_ctx *c, rt_hierarchy_info *out) {
     out->two_child_nodes = S.bvh2_nodes ? (uint32_t)c->n_bvh2_nodes : 0u;
     out->two_child_linear = S.bvh2_nodes ? S.n_bvh2_linear : 0u;
     out->regrouping_kernel = (!S.ray_marching && S.bvh2_nodes && S.diffuse && !c->has_refractive && S.max_ray_bounces >= 1u) ? 1u : 0u;
+    if (c->tile_sky_words != 0u && c->tile_sky_key[0] != ~0ull) {
+        RT_HIP(c, hipSetDevice(c->device));
+        RT_HIP(c, hipStreamSynchronize(c->tile_sky_stream));
+        std::vector<uint32_t> words(c->tile_sky_words);
+        RT_HIP(c, hipMemcpy(words.data(), c->tile_sky.ptr, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const uint32_t all = 0x01010101u >> (8u * (4u - c->tile_sky_waves));
+        for (uint32_t w : words) out->sky_workgroups += (w == all) ? 1u : 0u;
+        out->classified_workgroups = c->tile_sky_words;
+    }
     return RT_OK;
 }
 

@@ -831,6 +831,61 @@ def test_random_scenes_through_the_hierarchy(pkg, orc, ctx, seed):
     assert np.array_equal(ctx.read_accum().view(np.uint32), lin.view(np.uint32))
 
 
+@pytest.mark.parametrize("name", ["scene3", "tex4"])
+@pytest.mark.parametrize("size", [(1000, 300), (257, 131), (64, 8), (7, 5)])
+def test_sky_tile_classification_changes_no_pixel(pkg, orc, ctx, name, size):
+    """Small scenes without glass are rendered with a tile classification in front (workgroups whose camera rays cannot
+    reach any object write the value of a miss without tracing).  RT_RENDER_NO_SKY_TILES renders without it: accumulator,
+    bytes and ray count are identical -- for whole frames, row ranges that do not start on a tile row, interleaved shares --
+    and a classification is never reused after the camera or an object has moved into what was sky."""
+    import torch
+    s = pkg.Scene(name)
+    s.desc.max_ray_bounces = 4
+    w, h = size
+    ctx.load(s, w, h)
+
+    def both(**kw):
+        out = []
+        for flags in (0, pkg.RT_RENDER_NO_SKY_TILES):
+            rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+            accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+            ctx.render_device(frame_index=1, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), flags=flags, **kw)
+            rays = ctx.stats()["rays_total"]
+            out.append((rgba.cpu().numpy(), accum.cpu().numpy(), rays))
+        a, b = out
+        assert a[2] == b[2], f"ray counts differ: {a[2]} / {b[2]} ({kw})"
+        assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[0], b[0]), f"frames differ ({kw})"
+        return a
+
+    whole = both()
+    info = ctx.hierarchy_info()
+    assert info["classified_workgroups"] > 0
+    if w * h >= 1000 * 300:
+        assert info["sky_workgroups"] > info["classified_workgroups"] // 10, "the test scenes show sky in a good part of the frame"
+    ref = orc.render(s.desc, s.camera(w, h), s.textures(), n_threads=8)
+    assert np.array_equal(whole[0], ref["rgba"]) and np.array_equal(whole[1].view(np.uint32), ref["accum"].view(np.uint32))
+    if h >= 24:
+        both(rows=(3, h - 5))
+        both(rows=(8, h), tile_row_stride=3)
+    # the camera turns towards the sky, then down to the ground: every former classification is wrong for the new view
+    for look in ((0.0, 3.0, -1.0), (0.0, -3.0, -1.0), (0.4, -0.3, -1.0)):
+        cam = pkg.make_camera((0.3, 1.5, 4.0), look, w, h)
+        ctx.set_camera(cam)
+        got = both()
+        ref = orc.render(s.desc, cam, s.textures(), n_threads=8)
+        assert np.array_equal(got[0], ref["rgba"]) and np.array_equal(got[1].view(np.uint32), ref["accum"].view(np.uint32)), f"camera {look}"
+    # an object moves into the sky part of the last view
+    k = next(i for i in range(s.desc.n_objects) if s.desc.objects[i].kind == pkg.RT_SPHERE)
+    o = pkg.rt_object.from_buffer_copy(s.desc.objects[k])
+    o.position = (C.c_float * 3)(0.8, 3.2, -2.0)
+    pkg.host().rth_object_update(C.byref(o))
+    ctx.update_objects(k, [o])
+    s.desc.objects[k] = o
+    got = both()
+    ref = orc.render(s.desc, cam, s.textures(), n_threads=8)
+    assert np.array_equal(got[0], ref["rgba"]) and np.array_equal(got[1].view(np.uint32), ref["accum"].view(np.uint32)), "moved object"
+
+
 @pytest.mark.parametrize("mode", ["whitted", "diffuse"])
 @pytest.mark.parametrize("many", [False, True])
 def test_unrotated_textured_spheres_on_the_camera_axes(pkg, orc, ctx, mode, many):
