@@ -1314,21 +1314,19 @@ RT_DEV bool tile_is_sky(const DevScene &S, const DevCamera &C, uint32_t x0, uint
     }
     return true;
 }
-// One thread per workgroup of a render launch with grid (grid_x, grid_y) and `waves` wavefronts per workgroup; the word's
-// byte k is wavefront k's tile (tiles outside the frame count as sky: they have no pixels).
-__global__ void __launch_bounds__(64) rt_tile_sky_kernel(const DevScene S, const DevCamera C, const DevFrame F, uint32_t grid_x, uint32_t grid_y, uint32_t waves,
-                                                          uint32_t *__restrict__ out) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+// Four threads per workgroup of a render launch with grid (grid_x, grid_y) and `waves` wavefronts per workgroup: thread k
+// writes byte k of the workgroup's word, wavefront k's tile (tiles outside the frame count as sky: they have no pixels;
+// bytes beyond `waves` are 0).
+__global__ void __launch_bounds__(256) rt_tile_sky_kernel(const DevScene S, const DevCamera C, const DevFrame F, uint32_t grid_x, uint32_t grid_y, uint32_t waves,
+                                                           uint8_t *__restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t idx = t >> 2, k = t & 3u;
     if (idx >= grid_x * grid_y) return;
     const uint32_t by = idx / grid_x, bx = idx - by * grid_x;
-    const uint32_t y0 = F.row_begin + (grid_y - 1u - by) * F.tile_row_step;
-    uint32_t word = 0u;
-    for (uint32_t k = 0; k < waves; k++) {
-        const uint32_t x0 = (bx * waves + k) * 8u;
-        const bool sky = x0 >= C.width || y0 >= F.row_end || tile_is_sky(S, C, x0, y0);
-        word |= (sky ? 1u : 0u) << (8u * k);
-    }
-    out[idx] = word;
+    const uint32_t y0 = F.row_begin + (grid_y - 1u - by) * F.tile_row_step, x0 = (bx * waves + k) * 8u;
+    uint8_t sky = 0u;
+    if (k < waves) sky = (x0 >= C.width || y0 >= F.row_end || tile_is_sky(S, C, x0, y0)) ? 1u : 0u;
+    out[t] = sky;
 }
 
 // ------------------------------------------------------------------------------------------------

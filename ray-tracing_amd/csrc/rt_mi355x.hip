@@ -661,7 +661,8 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         const uint64_t k1 = ((uint64_t)rb << 40) | ((uint64_t)re << 16) | ((uint64_t)stride << 4) | (uint64_t)waves_per_block;
         if (k0 != c->tile_sky_key[0] || k1 != c->tile_sky_key[1] || c->tile_sky_words != blocks) {
             RT_HIP(c, c->tile_sky.ensure(blocks));
-            hipLaunchKernelGGL(rt_tile_sky_kernel, dim3((blocks + 63u) / 64u), dim3(64), 0, s, S, c->camera, F, grid.x, grid.y, waves_per_block, c->tile_sky.ptr);
+            hipLaunchKernelGGL(rt_tile_sky_kernel, dim3((4u * blocks + 255u) / 256u), dim3(256), 0, s, S, c->camera, F, grid.x, grid.y, waves_per_block,
+                               reinterpret_cast<uint8_t *>(c->tile_sky.ptr));
             RT_HIP(c, hipGetLastError());
             c->tile_sky_key[0] = k0; c->tile_sky_key[1] = k1; c->tile_sky_words = blocks; c->tile_sky_waves = waves_per_block; c->tile_sky_stream = s;
         }
