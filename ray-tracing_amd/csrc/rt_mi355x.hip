@@ -1036,6 +1036,7 @@ int32_t rt_get_stats(rt_ctx *c, rt_stats *out) {
 }
 
 int32_t rt_get_hierarchy_info(rt_ctx *c, rt_hierarchy_info *out) {
+    RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!out) return fail(c, RT_ERR_INVALID_ARGUMENT, "out is null");
     if (!c->has_scene) return fail(c, RT_ERR_STATE, "scene not set");
@@ -1056,6 +1057,7 @@ int32_t rt_get_hierarchy_info(rt_ctx *c, rt_hierarchy_info *out) {
         out->classified_workgroups = c->tile_sky_words;
     }
     return RT_OK;
+    RT_GUARD_END(c)
 }
 
 void *rt_context_stream(rt_ctx *c) { return c ? (void *)c->stream : nullptr; }
