@@ -886,6 +886,63 @@ def test_sky_tile_classification_changes_no_pixel(pkg, orc, ctx, name, size):
     assert np.array_equal(got[0], ref["rgba"]) and np.array_equal(got[1].view(np.uint32), ref["accum"].view(np.uint32)), "moved object"
 
 
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_sky_tile_classification_on_random_scenes_and_cameras(pkg, ctx, seed):
+    """The tile classification must never call a tile sky that a camera ray leaves towards an object.  Random small scenes of
+    every primitive kind (rotated, tiny and huge, bounded and unbounded planes with unnormalised normals, an object around
+    the camera) seen from random cameras, some inside objects, some looking away from everything: the frame with the
+    classification equals the frame without it, pixel for pixel and ray for ray, on every one of 40 views per scene."""
+    import torch
+    rng = np.random.default_rng(7700 + seed)
+    mats = [make_material(pkg, albedo=tuple(rng.uniform(0.2, 0.9, 3)), roughness=float(rng.uniform(0.2, 1.0)), ambience=0.4) for _ in range(4)]
+    objs = []
+    for i in range(int(rng.integers(1, 12))):
+        pos = tuple(float(a) for a in rng.uniform(-6, 6, 3))
+        rot = tuple(float(a) for a in rng.uniform(-180, 180, 3))
+        m = int(rng.integers(0, 4))
+        kind = int(rng.integers(0, 6))
+        if kind == 0:
+            objs.append(make_object(pkg, pkg.RT_SPHERE, m, position=pos, rotation_axis=rot if i % 2 else (0.0, 0.0, 0.0), radius=float(10 ** rng.uniform(-1.5, 0.8))))
+        elif kind == 1:
+            objs.append(make_object(pkg, pkg.RT_CUBOID, m, position=pos, rotation_axis=rot, dimension=tuple(float(a) for a in rng.uniform(0.05, 2.0, 3))))
+        elif kind == 2:
+            objs.append(make_object(pkg, pkg.RT_CYLINDER, m, position=pos, rotation_axis=rot, radius=0.3, height=1.0))
+        elif kind == 3:
+            objs.append(make_object(pkg, pkg.RT_CONE, m, position=pos, rotation_axis=rot, radius=float(rng.uniform(0.2, 1.5)), height=float(rng.uniform(0.4, 2.0))))
+        elif kind == 4:
+            v1 = np.array(pos)
+            objs.append(make_object(pkg, pkg.RT_TRIANGLE, m, v1=tuple(v1), v2=tuple(v1 + rng.uniform(-3, 3, 3)), v3=tuple(v1 + rng.uniform(-3, 3, 3))))
+        else:
+            nrm = rng.uniform(-1, 1, 3) * float(rng.choice([0.2, 1.0, 5.0]))
+            objs.append(make_object(pkg, pkg.RT_PLANE, m, normal=tuple(float(a) for a in nrm), point=pos,
+                                    max_dist=(float(rng.uniform(0.5, 8)), float(rng.uniform(0.5, 8))), has_max_dist=int(rng.integers(0, 2))))
+    lights = [make_light(pkg, pkg.RT_POSITIONAL, (1, 1, 1), (2.0, 6.0, 3.0), 30.0)]
+    sb = SceneBuilder(pkg, objs, mats, lights, max_ray_bounces=3, shadow_casting=seed % 2, ambient_color=(0.1, 0.2, 0.3))
+    ctx.set_scene(sb.desc)
+    w, h = 136, 88
+    sky_seen = 0
+    for view in range(40):
+        if view % 5 == 0 and objs[0].kind != pkg.RT_PLANE:
+            eye = tuple(float(a) for a in (np.array(objs[0].position[:]) + rng.uniform(-0.05, 0.05, 3)))   # inside / next to the first object
+        else:
+            eye = tuple(float(a) for a in rng.uniform(-9, 9, 3))
+        look = rng.uniform(-1, 1, 3)
+        look = tuple(float(a) for a in (look / max(np.linalg.norm(look), 1e-3)))
+        ctx.set_camera(pkg.make_camera(eye, look, w, h))
+        out = []
+        for flags in (0, pkg.RT_RENDER_NO_SKY_TILES):
+            rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+            accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+            ctx.render_device(frame_index=1, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), flags=flags)
+            rays = ctx.stats()["rays_total"]   # waits for the context's stream
+            out.append((rgba.cpu().numpy(), accum.cpu().numpy(), rays))
+        a, b = out
+        assert a[2] == b[2], f"scene {seed} view {view}: ray counts {a[2]} / {b[2]}"
+        assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[0], b[0]), f"scene {seed} view {view} (eye {eye}, look {look})"
+        sky_seen += ctx.hierarchy_info()["sky_workgroups"]
+    assert sky_seen > 0 or any(o.kind == pkg.RT_PLANE and not o.has_max_dist for o in objs)
+
+
 @pytest.mark.parametrize("mode", ["whitted", "diffuse"])
 @pytest.mark.parametrize("many", [False, True])
 def test_unrotated_textured_spheres_on_the_camera_axes(pkg, orc, ctx, mode, many):
