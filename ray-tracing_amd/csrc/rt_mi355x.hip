@@ -658,7 +658,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
                            !(p->flags & RT_RENDER_NO_SKY_TILES);
     if (sky_tiles) {
         const uint64_t k0 = ((uint64_t)c->scene_serial << 32) | ((uint64_t)c->camera.width << 16) | (uint64_t)c->camera.height;
-        const uint64_t k1 = ((uint64_t)rb << 40) | ((uint64_t)re << 16) | ((uint64_t)stride << 4) | (uint64_t)waves_per_block;
+        const uint64_t k1 = ((uint64_t)rb << 44) | ((uint64_t)re << 20) | ((uint64_t)stride << 4) | (uint64_t)waves_per_block;   // stride <= 4096: 13 bits
         if (k0 != c->tile_sky_key[0] || k1 != c->tile_sky_key[1] || c->tile_sky_words != blocks) {
             RT_HIP(c, c->tile_sky.ensure(blocks));
             hipLaunchKernelGGL(rt_tile_sky_kernel, dim3((4u * blocks + 255u) / 256u), dim3(256), 0, s, S, c->camera, F, grid.x, grid.y, waves_per_block,
