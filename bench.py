@@ -19,9 +19,12 @@ torch.distributed.run it is one of the ranks.  The frame is split the way the re
   frames   (opt-in) whole frames of a sequence per rank, no collective.
 The timing is barrier + synchronize on both sides and the maximum over ranks.  Rank 0 prints one JSON line.
 
-Without --workload the line is the default workload's, and a short second measurement (2 steps) of BASELINE.json's
-multi-GPU configuration -- the 8K / 10 000-sphere / 64-spp frame, sharded by sample index when N > 1 -- rides along under
-the key "config5" (--no-config5 leaves it out), so that one run per GPU count tells how that frame scales as well.
+Without --workload the line is the default workload's, and three short measurements ride along in the same line
+(--no-riders leaves them out): under "config5" BASELINE.json's multi-GPU configuration -- the 8K / 10 000-sphere / 64-spp
+frame, sharded by sample index when N > 1 -- so that one run per GPU count tells how that frame scales as well; and, at
+N = 1, under "changed_frames" the frames the reference renders when something changed (src/app.rs:214-248: every frame it
+renders without accumulation): the default scene with a new camera pose every step (rt_set_camera + render) and the
+all-primitives scene with its update function's object motion every step (rt_update_objects + render).
 """
 from __future__ import annotations
 
@@ -53,7 +56,12 @@ WORKLOADS = {
     "spheres10k_8k": ("spheres10k", 7680, 4320, 5, True, 64, "samples", "10 000 diffuse spheres, 7680x4320, 64 spp accumulated per frame"),
     "spheres10k_4k": ("spheres10k", 3840, 2160, 5, True, 1, "rows", "10 000 diffuse spheres, 3840x2160, 1 spp per step (accumulating)"),
     "scene3_800x600": ("scene3", 800, 600, None, False, 1, "rows", "reference default scene at its default viewport (800x600, max 4 bounces): BASELINE config 1"),
+    # frames in which something changed since the previous one (the only frames the reference renders without accumulation)
+    "scene3_4k_moving": ("scene3", 3840, 2160, 5, False, 1, "rows", "reference default scene, 3840x2160, 1 spp, max 5 bounces, a new camera pose every step (rt_set_camera + render)"),
+    "scene1_4k_animated": ("scene1", 3840, 2160, 5, False, 1, "rows", "all-primitives textured scene, 3840x2160, 1 spp, max 5 bounces, its cuboid turned every step (rt_update_objects + render)"),
 }
+MOTION = {"scene3_4k_moving": "camera", "scene1_4k_animated": "objects"}
+N_POSES = 64   # camera poses / object states a moving workload cycles through
 
 
 def spawn_ranks(n: int) -> int:
@@ -87,8 +95,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--consecutive-launches", action="store_true",
                     help="multi-sample workloads: one rt_render_device call per sample instead of one rt_render_samples_device call per frame (profiling runs)")
-    ap.add_argument("--no-config5", action="store_true",
-                    help="default workload only: without the ride-along measurement of the 8K / 10 000-sphere / 64-spp frame")
+    ap.add_argument("--no-config5", "--no-riders", dest="no_config5", action="store_true",
+                    help="default workload only: without the ride-along measurements (8K / 10 000-sphere / 64-spp frame; moving camera; animated scene)")
     ap.add_argument("--keep-accum-store", action="store_true",
                     help="non-accumulating workloads: also write the frame's linear value to the accumulator (default: RT_RENDER_SKIP_ACCUM_STORE)")
     ap.add_argument("--no-sky-tiles", action="store_true",
@@ -156,6 +164,27 @@ def main() -> None:
             scene.desc.max_ray_bounces = bounces
         ctx = pkg.Context(device_index)
         ctx.load(scene, width, height)
+        # workloads in which something changes before every frame: the states are built once, a step only hands one over
+        motion = MOTION.get(workload)
+        poses, moved = [], []
+        if motion == "camera":
+            import math
+            for k in range(N_POSES):   # a small orbit around the scene's own camera (src/bin/scene3.rs: position (0,2,5), direction (0,0,-1))
+                a = 2.0 * math.pi * k / N_POSES
+                poses.append(pkg.make_camera((0.25 * math.sin(a), 2.0 + 0.1 * math.cos(a), 5.0), (0.05 * math.sin(a + 1.0), 0.02 * math.cos(a), -1.0), width, height))
+        elif motion == "objects":
+            import ctypes
+            for k in range(N_POSES):   # the scene's update function turns its cuboid, object 3 (src/bin/scene1.rs:13-24)
+                o = pkg.rt_object.from_buffer_copy(scene.desc.objects[3])
+                o.rotation_axis[1] += 360.0 * k / N_POSES
+                pkg.host().rth_object_update(ctypes.byref(o))
+                moved.append((pkg.rt_object * 1)(o))
+
+        def apply_motion(i: int) -> None:
+            if motion == "camera":
+                ctx.set_camera(poses[i % N_POSES])
+            elif motion == "objects":
+                ctx.update_objects_array(3, moved[i % N_POSES])
 
         # every buffer a step touches exists before the timed loop: frame, accumulator, and the collectives' send/receive blocks
         xch = pkg.FrameExchange(dist, height, width, rank, world, device="cuda", backend=backend, force_collectives=use_dist)
@@ -173,10 +202,11 @@ def main() -> None:
         # it), so the frame's linear value is not written to it: 4 instead of 20 bytes stored per pixel.  The parity tests keep it.
         skip_store = not args.keep_accum_store
 
-        def render(sample_index: int, acc: bool = accumulate, rows=rows_arg, events: bool = False) -> None:
+        def render(sample_index: int, acc: bool = accumulate, rows=rows_arg, events: bool = False, skip: bool = None) -> None:
             # the timed region is bracketed by this script's own events, so the library's per-launch timing events are off
+            skip = skip_store if skip is None else skip
             ctx.render_device(frame_index=sample_index if acc else 1, accumulate=acc, seed=0x5EED,
-                              flags=(pkg.RT_RENDER_SKIP_ACCUM_STORE if (skip_store and not acc) else 0) | (pkg.RT_RENDER_NO_SKY_TILES if args.no_sky_tiles else 0),
+                              flags=(pkg.RT_RENDER_SKIP_ACCUM_STORE if (skip and not acc) else 0) | (pkg.RT_RENDER_NO_SKY_TILES if args.no_sky_tiles else 0),
                               rows=(rows[0], rows[1]) if rows else None, tile_row_stride=rows[2] if rows else 0,
                               d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh, no_timing=not events, collect_events=events)
 
@@ -200,6 +230,7 @@ def main() -> None:
                 k0.record(stream)
             if shard == "samples":
                 accum.zero_()
+            apply_motion(i)
             ids = sample_ids(i)
             if batched and len(ids) > 1:
                 # the samples of a frame in one call: the library overlaps launches of interleaved shares of the rows
@@ -257,9 +288,19 @@ def main() -> None:
         launches_per_step = len(sample_ids(0))
         # average launch duration of the render kernel(s), from events on the launch stream: around each step's render launches
         # when the step also has collectives, around the whole timed loop (launches back to back) otherwise
-        if batched:
-            # the batch call overlaps launches of row shares, so the timed region does not show the duration of a launch: a few
-            # whole-frame launches, one after the other, are timed for the roofline line after the timed region
+        chained = batched and kernel_name(pkg, scene, spp) == "rt_wf_chain_kernel"
+        if chained:
+            # one launch renders all samples of the frame: its duration is the step's (timed once more here, alone on the stream)
+            p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ids = sample_ids(warmup)
+            p0.record(stream)
+            ctx.render_samples_device(ids[0], len(ids), seed=0x5EED, rows=(rows_arg[0], rows_arg[1]) if rows_arg else None,
+                                      tile_row_stride=rows_arg[2] if rows_arg else 0, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh)
+            p1.record(stream)
+            torch.cuda.synchronize()
+            kernel_ms = p0.elapsed_time(p1)
+            launches_per_step = 1
+        elif batched:
             probe = min(8, launches_per_step)
             p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             render(1, acc=True)
@@ -274,31 +315,67 @@ def main() -> None:
         else:
             kernel_ms = ev0.elapsed_time(ev1) / (steps * launches_per_step)
         exchange_ms = sum(a.elapsed_time(b) for a, b in exchange_events) / steps if exchange_events else 0.0
-        # rays per step: deterministic scenes trace the same rays every frame; random modes vary by < 0.1 % between sample sets,
-        # so the count of the first timed step's sample set stands for every step (untimed pass: one stats read-back per render)
-        rays_rank = 0
-        for idx in sample_ids(warmup):
-            render(idx, acc=True if shard == "samples" else accumulate)
-            rays_rank += ctx.stats()["rays_total"]
+        # Rays of the timed steps (untimed passes: one stats read-back per render).  Deterministic scenes trace the same rays
+        # every frame; random modes vary by < 0.1 % between sample sets, so the first timed step's set stands for every step;
+        # moving workloads are counted state by state.  rays_sky_tiles: camera rays that the tile classification settled
+        # (workgroups of nothing but sky) -- the reference traces them, this backend does not, so they are reported apart.
+        def count_step(i: int):
+            apply_motion(i)
+            total = sky = 0
+            ids = sample_ids(i)
+            if chained:
+                ctx.render_samples_device(ids[0], len(ids), seed=0x5EED, rows=(rows_arg[0], rows_arg[1]) if rows_arg else None,
+                                          tile_row_stride=rows_arg[2] if rows_arg else 0, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh)
+                return ctx.stats()["rays_total"], 0
+            for idx in ids:
+                render(idx, acc=True if shard == "samples" else accumulate)
+                st = ctx.stats()
+                total += st["rays_total"]
+                sky += st["rays_sky_tiles"]
+            return total, sky
+        if motion:
+            per_state = [count_step(k) for k in range(N_POSES)]
+            rays_timed = sum(per_state[(warmup + i) % N_POSES][0] for i in range(steps))
+            sky_timed = sum(per_state[(warmup + i) % N_POSES][1] for i in range(steps))
+        else:
+            r1, s1 = count_step(warmup)
+            rays_timed, sky_timed = r1 * steps, s1 * steps
+        rays_rank = rays_timed // steps
+
+        # the same frames with the reference's write of the linear value to Renderer.accumulated (src/renderer.rs:68) left in
+        ms_with_store = None
+        if not accumulate and shard == "none" and skip_store:
+            k2 = max(1, min(steps, 300))
+            for i in range(10):
+                apply_motion(i); render(1, skip=False)
+            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            q0.record(stream)
+            for i in range(k2):
+                apply_motion(i); render(1, skip=False)
+            q1.record(stream)
+            torch.cuda.synchronize()
+            ms_with_store = q0.elapsed_time(q1) / k2
 
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        r = torch.tensor([float(rays_rank)], dtype=torch.float64, device="cuda")
+        r = torch.tensor([float(rays_timed), float(sky_timed)], dtype=torch.float64, device="cuda")
         if use_dist:
             if xch.staged:
                 t, r = t.cpu(), r.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(r, op=dist.ReduceOp.SUM)
         elapsed_max = float(t.item())
-        rays_per_step_all = float(r.item())
+        rays_all, sky_all = float(r[0].item()), float(r[1].item())
 
         out = None
         if rank == 0:
             # algorithmic FLOPs of one launch: event counts of a (slower, untimed) counting render times the per-event constants
             render(1, acc=False, events=True)
             st = ctx.stats()
-            flops = pkg.algorithmic_flops(st)
+            flops = pkg.algorithmic_flops(st) * (spp if chained else 1)   # a launch of the chain kernel renders all samples of the frame
             achieved = flops / (kernel_ms * 1e-3) / 1e12
-            value = rays_per_step_all * steps / elapsed_max / 1e6
+            value = rays_all / elapsed_max / 1e6
+            value_traced = (rays_all - sky_all) / elapsed_max / 1e6
             traffic, traffic_note = measured_traffic(workload, pkg.LIB_PATH)
             hinfo = ctx.hierarchy_info()
             if args.no_sky_tiles:
@@ -311,6 +388,8 @@ def main() -> None:
             out = {
                 "metric": "Mrays/sec (primary+secondary) and frame ms at 4K",
                 "value": round(value, 2),
+                # the same without the camera rays that the tile classification settled without tracing them
+                "value_traced_only": round(value_traced, 2),
                 "unit": "Mrays/s",
                 "n_gpus": world,
                 "steps": steps,
@@ -323,7 +402,8 @@ def main() -> None:
                 "data": "synthetic",
                 "config": {"workload": f"{workload}: {description}", "width": width, "height": height,
                            "max_ray_bounces": int(scene.desc.max_ray_bounces), "samples_per_step": spp,
-                           "rays_per_step_per_rank": int(rays_rank), "sharding": shard, "clock_prewarm_ms": int(CLOCK_PREWARM_S * 1e3),
+                           "rays_per_step_per_rank": int(rays_rank), "traced_rays_per_step": int(round((rays_all - sky_all) / steps)),
+                           "sky_tile_rays_per_step": int(round(sky_all / steps)), "sharding": shard, "clock_prewarm_ms": int(CLOCK_PREWARM_S * 1e3),
                            "accumulator_store": "n/a (accumulating)" if accumulate or shard == "samples" else ("skipped" if skip_store else "written"),
                            "sky_tiles": sky_tiles,
                            "ranks": world, "backend": backend if use_dist else "none", "exchange_ms_per_step": round(exchange_ms, 4),
@@ -331,14 +411,15 @@ def main() -> None:
                                           "all_gather(rgba8 tile rows)" if shard == "rows" else
                                           ("reduce_scatter(f32 accum) + all_gather(rgba8 bands)" if xch.reduce_scatter else "all_reduce(f32 accum) + all_gather(rgba8 bands)")),
                            "parallelism": f"{shard}-sharded x{world}" if world > 1 else "single GPU",
-                       "samples_call": ("rt_render_samples_device (one call per frame: launches of four interleaved row shares overlap; "
-                                        "roofline.kernel_ms is a whole-frame launch timed alone)") if batched else "rt_render_device per sample"},
+                           "samples_call": ("rt_render_samples_device (one launch per frame: every pixel's samples are traced one after the other by the "
+                                            "wavefront that holds the pixel; roofline.kernel_ms is that launch)") if chained else
+                                           ("rt_render_samples_device" if batched else "rt_render_device per sample")},
                 "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": traffic,
                              # the 157.3 TFLOP/s peak is one FMA (2 flops) per lane every 2 cycles; bit-exact parity keeps multiplies
                              # and adds unfused, so one flop per lane-instruction (half of it) bounds this code
                              "frac_of_unfused_peak": round(achieved / (FP32_VALU_PEAK_TFLOPS / 2.0), 5),
-                             "kernel": kernel_name(pkg, scene),
+                             "kernel": kernel_name(pkg, scene, spp if batched else 1),
                              "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": int(flops),
                              "note": "FP32 vector (VALU) roofline: this path has no dense contraction, so no MFMA"},
             }
@@ -351,17 +432,39 @@ def main() -> None:
                 alg = width * height * (36 if (accumulate or shard == "samples") else 4)
                 out["roofline"]["hbm_view"] = {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
                                                "algorithmic_bytes": alg, "traffic_over_algorithmic": round(traffic / alg, 2)}
+            if ms_with_store is not None:
+                out["config"]["ms_per_step_with_accumulator_store"] = round(ms_with_store, 4)
+            if motion:
+                out["config"]["per_step_host_calls"] = "rt_set_camera + rt_render_device" if motion == "camera" else "rt_update_objects (1 object) + rt_render_device"
             if scene.desc.ray_marching:
                 # one sdfs() call evaluates the whole SDF list once (src/ray_marching/ray_marching.rs:24-107)
                 out["config"]["sdf_list_evals_per_s"] = round(st["sdfs_call"] / (kernel_ms * 1e-3), 1)
             if world == 1 and want_cpu_baseline:   # a reported baseline of the single-GPU line only
-                out["cpu_baseline"] = cpu_baseline(pkg, scene, width, height, accumulate)
+                cb = cpu_baseline(pkg, scene, width, height, accumulate)
+                out["cpu_baseline"] = cb
+                # the north star's ratio with its spread: all rays of the frame (what the CPU traces) and traced rays only
+                out["vs_cpu_baseline"] = {"all_rays": {"median": round(value / cb["value"], 1), "min": round(value / cb["max"], 1), "max": round(value / cb["min"], 1)},
+                                          "traced_rays_only": {"median": round(value_traced / cb["value"], 1), "min": round(value_traced / cb["max"], 1),
+                                                               "max": round(value_traced / cb["min"], 1)}}
         ctx.close()
         del xch, rgba, accum
         torch.cuda.empty_cache()
         return out
 
     out = measure(args.workload, args.steps, args.warmup, not args.no_cpu_baseline, args.shard)
+    if with_config5 and world == 1 and not use_dist:
+        # the frames the reference renders when something changed (camera pose / object motion before every frame)
+        changed = {}
+        for wl, k in (("scene3_4k_moving", 500), ("scene1_4k_animated", 300)):
+            extra = measure(wl, k, 20, False, None)
+            if extra is not None:
+                changed[wl] = {"workload": extra["config"]["workload"], "ms_per_step": extra["ms_per_step"], "value": extra["value"],
+                               "value_traced_only": extra["value_traced_only"], "unit": extra["unit"], "steps": extra["steps"],
+                               "ms_per_step_with_accumulator_store": extra["config"].get("ms_per_step_with_accumulator_store"),
+                               "per_step_host_calls": extra["config"]["per_step_host_calls"], "kernel_ms": extra["roofline"]["kernel_ms"],
+                               "frac": extra["roofline"]["frac"]}
+        if out is not None:
+            out["changed_frames"] = changed
     if with_config5:
         # BASELINE's multi-GPU configuration (8K, 10 000 spheres, 64 spp, sharded by sample index) rides along as a short
         # second measurement, so that a run at N GPUs of the default workload also says how that frame scales
@@ -380,15 +483,18 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def kernel_name(pkg, scene) -> str:
-    """The kernel rt_render_device launches for this scene (the choice in ray-tracing_amd/csrc/rt_mi355x.hip)."""
+def kernel_name(pkg, scene, samples: int = 1) -> str:
+    """The kernel rt_render_device (samples == 1) or rt_render_samples_device launches for this scene (the choice in
+    ray-tracing_amd/csrc/rt_mi355x.hip)."""
     d = scene.desc
     if d.ray_marching:
         return "rt_march_kernel"
     refractive = any(d.materials[i].kind == pkg.RT_REFRACTIVE for i in range(d.n_materials))
     bounded = sum(1 for i in range(d.n_objects) if d.objects[i].kind not in (pkg.RT_PLANE, pkg.RT_UNION, pkg.RT_SUBSTRACTION))
     if d.diffuse and not refractive and d.max_ray_bounces >= 1:
-        return "rt_wf_diffuse_kernel" if bounded >= 32 else "rt_refill_diffuse_kernel"
+        if bounded >= 32:
+            return "rt_wf_chain_kernel" if samples > 1 else "rt_wf_diffuse_kernel"
+        return "rt_refill_diffuse_kernel"
     return "rt_trace_kernel"
 
 
@@ -431,26 +537,34 @@ def cpu_baseline(pkg, scene, width, height, accumulate) -> dict:
     budget_rows = height if not scene.desc.ray_marching and scene.desc.n_objects < 100 else max(8, height // 48)
     n_bands = max(1, budget_rows // 8)
     starts = [int(round(i * (height - 8) / max(1, n_bands - 1))) // 8 * 8 for i in range(n_bands)] if n_bands * 8 < height else None
-    rays = 0
-    t0 = time.perf_counter()
-    if starts is None:
-        # cheap scenes: whole frames, repeated until the cores have worked for about 20 core-seconds
-        orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, ray_dirs=dirs)   # warm-up (page faults, thread start)
+    def one_pass():
+        """(rays, seconds) of one pass over the sample."""
         t0 = time.perf_counter()
-        frames = 0
-        while frames < 3 or (time.perf_counter() - t0) * threads < 20.0:
+        rays = 0
+        if starts is None:
             r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, want_counters=True, ray_dirs=dirs)
-            rays += sum(r["counters"][:5])
-            frames += 1
-        sample = f"{frames} full {width}x{height} frames"
-    else:
-        for y in sorted(set(starts)):
-            r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, want_counters=True, rows=(y, y + 8), ray_dirs=dirs)
-            rays += sum(r["counters"][:5])
-        sample = f"{len(set(starts))} evenly spaced 8-row bands of the {width}x{height} frame"
-    dt = time.perf_counter() - t0
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": sample + f", {rays} rays in {dt:.2f} s; CPU restatement of the reference (Rust toolchain unavailable)"}
+            rays = sum(r["counters"][:5])
+        else:
+            for y in sorted(set(starts)):
+                r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, want_counters=True, rows=(y, y + 8), ray_dirs=dirs)
+                rays += sum(r["counters"][:5])
+        return rays, time.perf_counter() - t0
+
+    one_pass()   # warm-up (page faults, thread start)
+    # repeated until the cores have worked for about 20 core-seconds, at least five times: the value is the median pass
+    rates, rays_all, t_all = [], 0, 0.0
+    while len(rates) < 5 or (t_all * threads < 20.0 and len(rates) < 200):
+        rays, dt = one_pass()
+        rates.append(rays / dt / 1e6)
+        rays_all += rays
+        t_all += dt
+    rates.sort()
+    median = rates[len(rates) // 2] if len(rates) % 2 else 0.5 * (rates[len(rates) // 2 - 1] + rates[len(rates) // 2])
+    what = f"full {width}x{height} frames" if starts is None else f"passes over {len(set(starts))} evenly spaced 8-row bands of the {width}x{height} frame"
+    return {"value": round(median, 3), "unit": "Mrays/s", "cores": threads, "kind": "port", "min": round(rates[0], 3), "max": round(rates[-1], 3),
+            "repeats": len(rates),
+            "sample": f"{len(rates)} {what}: median {median:.1f}, min {rates[0]:.1f}, max {rates[-1]:.1f} Mrays/s; {rays_all} rays in {t_all:.2f} s; "
+                      "CPU restatement of the reference (Rust toolchain unavailable)"}
 
 
 if __name__ == "__main__":

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 typedef struct rt_ctx rt_ctx;
 
@@ -197,6 +197,8 @@ typedef struct rt_stats {
     double last_kernel_ms;   /* HIP-event time of the last render's kernel(s) on the launch stream (0 if no_timing) */
     double last_copy_ms;     /* D2H time of the last rt_render (0 for rt_render_device)            */
     uint64_t frames_rendered;
+    uint64_t rays_sky_tiles; /* part of rays_total: camera rays of workgroups that the tile classification (see
+                              * RT_RENDER_NO_SKY_TILES) gave the value of a miss without tracing them; the reference traces them */
 } rt_stats;
 
 /* Arguments of one frame.  Mirrors the per-frame state of Renderer (src/renderer.rs:13-18) as
@@ -228,14 +230,14 @@ typedef enum rt_render_flag {
      * src/renderer.rs:67-68) unless this flag is set: a caller that only displays `img` and never reads the accumulator
      * back saves 16 of the 20 bytes written per pixel.  Ignored when accumulate != 0. */
     RT_RENDER_SKIP_ACCUM_STORE = 2,
-    /* rt_render_samples_device deals the tile rows to interleaved shares on streams of its own only for frames large enough
-     * to gain from it; this flag makes it do so whatever the frame size (tests of that path on small frames). */
-    RT_RENDER_SAMPLE_SHARES = 4,
+    /* Value 4 belonged to a flag of ABI version 2 (RT_RENDER_SAMPLE_SHARES) that no longer has a meaning: accepted and ignored. */
+    RT_RENDER_RESERVED_4 = 4,
     /* Small scenes (linear scan) are rendered with a per-tile classification in front: 8x8-pixel tiles whose camera rays cannot
      * reach any object (by the objects' bounding spheres against the tile's pyramid of rays) get the value of a miss without
      * being traced.  The classification is recomputed whenever the scene, the camera or the rows of the launch change.  This flag
      * renders without it (A/B runs and tests that compare the two). */
-    RT_RENDER_NO_SKY_TILES = 8
+    RT_RENDER_NO_SKY_TILES = 8,
+    RT_RENDER_ALL_FLAGS = 15   /* any other bit in params.flags is refused with RT_ERR_INVALID_ARGUMENT */
 } rt_render_flag;
 
 /* Creates a context bound to HIP device `device_id` (one context per GPU; one process per GPU
@@ -299,9 +301,10 @@ int32_t rt_render_device_noalloc(rt_ctx *ctx, const rt_render_params *params, vo
 /* sample_count accumulating frames in one call: frame_index = params->frame_index, +1, ..., the pixels, accumulator and frame
  * of that many rt_render_device calls (the loop of App3D::run around Renderer::render, src/app.rs:248 with
  * src/renderer.rs:59-66, when a caller accumulates a fixed number of samples).  params->accumulate must be set;
- * collect_events is not supported.  Large diffuse scenes are rendered as interleaved shares of the tile rows on streams of
- * the library's own, which overlap; the caller's stream waits for them before it continues, so the call is asynchronous
- * like rt_render_device.  Afterwards rt_get_stats reports the rays of the last sample. */
+ * collect_events is not supported.  Large diffuse scenes are rendered by ONE launch in which each pixel's samples are traced
+ * one after the other and added in frame order (the order of `accumulated[pos] += p` over consecutive frames), so the
+ * accumulator is read and written once per call; other scenes by one launch per sample.  Asynchronous like rt_render_device.
+ * Afterwards rt_get_stats reports the rays of the whole call. */
 int32_t rt_render_samples_device(rt_ctx *ctx, const rt_render_params *params, uint32_t sample_count, void *d_rgba8, void *d_accum,
                                  void *stream);
 

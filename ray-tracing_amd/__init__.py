@@ -31,7 +31,7 @@ RT_SPHERE, RT_TRIANGLE, RT_CUBOID, RT_PLANE, RT_CYLINDER, RT_CONE, RT_UNION, RT_
 RT_REFLECTIVE, RT_REFRACTIVE = 0, 1
 RT_DIRECTIONAL, RT_POSITIONAL, RT_SPHERICAL_POSITIONAL = 0, 1, 2
 RT_MATH_POWF, RT_MATH_ATANF, RT_MATH_SQRT = 0, 1, 2
-RT_RENDER_ONE_LANE_PER_PIXEL, RT_RENDER_SKIP_ACCUM_STORE, RT_RENDER_SAMPLE_SHARES, RT_RENDER_NO_SKY_TILES = 1, 2, 4, 8
+RT_RENDER_ONE_LANE_PER_PIXEL, RT_RENDER_SKIP_ACCUM_STORE, RT_RENDER_NO_SKY_TILES = 1, 2, 8
 
 COUNTER_NAMES = [
     "rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "rays_march", "raygen",
@@ -115,7 +115,7 @@ class rt_camera_desc(C.Structure):
 
 class rt_stats(C.Structure):
     _fields_ = [("rays_total", C.c_uint64), ("counters", C.c_uint64 * RT_CNT_COUNT), ("last_kernel_ms", C.c_double),
-                ("last_copy_ms", C.c_double), ("frames_rendered", C.c_uint64)]
+                ("last_copy_ms", C.c_double), ("frames_rendered", C.c_uint64), ("rays_sky_tiles", C.c_uint64)]
 
 
 class rt_hierarchy_info(C.Structure):
@@ -356,6 +356,10 @@ class Context:
         arr = (rt_object * len(objects))(*objects)
         self._check(self._l.rt_update_objects(self._ctx, first, len(objects), arr), "rt_update_objects")
 
+    def update_objects_array(self, first: int, array) -> None:
+        """rt_update_objects with a ready ctypes array of rt_object (no per-call conversion: animation loops)."""
+        self._check(self._l.rt_update_objects(self._ctx, first, len(array), array), "rt_update_objects")
+
     def read_ray_directions(self) -> np.ndarray:
         """rt_read_ray_directions: Camera.ray_directions as an (h, w, 3) float32 array."""
         out = np.empty((self.height, self.width, 3), dtype=np.float32)
@@ -436,6 +440,7 @@ class Context:
         d["last_kernel_ms"] = float(s.last_kernel_ms)
         d["last_copy_ms"] = float(s.last_copy_ms)
         d["frames_rendered"] = int(s.frames_rendered)
+        d["rays_sky_tiles"] = int(s.rays_sky_tiles)
         return d
 
     def hierarchy_info(self) -> dict:

@@ -656,6 +656,17 @@ RT_DEV void store_pixel(const DevFrame &F, uint32_t pos, f3 p, float4 a) {
     __builtin_nontemporal_store(r | (g << 8) | (b << 16) | (a8 << 24), &F.rgba[pos]);
 }
 
+// The tail of the same for a pixel whose samples of several accumulating frames were added by the caller, in frame order and
+// starting from the entry's previous value (`self.accumulated[pos] += p` once per frame, src/renderer.rs:60): writes the entry
+// back and packs it as the LAST of those frames does (:62-66 with that frame's frame_index).
+RT_DEV void store_summed(const DevFrame &F, uint32_t pos, float4 a, uint32_t last_frame_index) {
+    reinterpret_cast<float4 *>(F.accum)[pos] = a;
+    const float fi = (float)last_frame_index;
+    const float cx = rt_clamp01_sse(a.x / fi), cy = rt_clamp01_sse(a.y / fi), cz = rt_clamp01_sse(a.z / fi), cw = rt_clamp01_sse(a.w / fi);
+    const uint32_t r = rt_as_u8(cx * 255.0f), g = rt_as_u8(cy * 255.0f), b = rt_as_u8(cz * 255.0f), a8 = rt_as_u8(cw + 255.0f);
+    __builtin_nontemporal_store(r | (g << 8) | (b << 16) | (a8 << 24), &F.rgba[pos]);
+}
+
 // The workgroup's row in the counter table (2-D grid, see lane_pixel).
 RT_DEV uint32_t rt_block_index() { return blockIdx.y * gridDim.x + blockIdx.x; }
 
@@ -732,13 +743,17 @@ __global__ void __launch_bounds__(256, BVH ? 5 : (REFR ? RT_REFR_WAVES : 7)) rt_
         if (tid == 0u) {   // one primary ray per pixel of the workgroup's tiles that lies inside the frame (see lane_pixel)
             const uint32_t x0 = blockIdx.x * (nthr >> 6) * 8u, y0 = F.row_begin + (gridDim.y - 1u - blockIdx.y) * F.tile_row_step;
             const uint32_t x1 = x0 + (nthr >> 6) * 8u < C.width ? x0 + (nthr >> 6) * 8u : C.width, y1 = y0 + 8u < F.row_end ? y0 + 8u : F.row_end;
-            F.counters[rt_block_index()] = (x1 > x0 && y1 > y0) ? (x1 - x0) * (y1 - y0) : 0u;
+            // bit 31 marks the row as "rays given the value of a miss by the classification" for rt_get_stats
+            F.counters[rt_block_index()] = ((x1 > x0 && y1 > y0) ? (x1 - x0) * (y1 - y0) : 0u) | 0x80000000u;
         }
         return;
     }
     // Camera.ray_directions[pos] (src/renderer.rs:49), requested before the tables are staged: the two memory round trips
     // of a wavefront's start overlap (lanes outside the frame take pixel 0's direction, which nobody uses)
-    const f3 rd_first = ld3(C.ray_dirs + 3u * (size_t)(in_frame ? py * C.width + px : 0u));
+    // (C.ray_dirs null, wave-uniform: the first frame after a camera change computes its directions itself, by the table's formula)
+    f3 rd_first;
+    if (C.ray_dirs) rd_first = ld3(C.ray_dirs + 3u * (size_t)(in_frame ? py * C.width + px : 0u));
+    else rd_first = camera_ray(C, in_frame ? px : 0u, in_frame ? py : 0u);
     for (uint32_t i = tid; i < (uint32_t)((EVENTS ? RT_CNT_COUNT : 0) + 1); i += nthr) s_cnt[i] = 0u;
     rt_pow_lds_init(s_pow);
     __syncthreads();
@@ -1137,7 +1152,10 @@ __global__ void __launch_bounds__(256, 8) rt_march_kernel(const DevScene S, cons
     const bool in_frame = lane_pixel(C, F, px, py);
     const f3 ro = ld3(C.position);
     // Camera.ray_directions[pos] (src/renderer.rs:49); lanes outside the frame take pixel 0's direction, which nobody uses
-    const f3 rd = ld3(C.ray_dirs + 3u * (size_t)(in_frame ? py * C.width + px : 0u));
+    // (C.ray_dirs null: the first frame after a camera change computes its directions itself, by the table's formula)
+    f3 rd;
+    if (C.ray_dirs) rd = ld3(C.ray_dirs + 3u * (size_t)(in_frame ? py * C.width + px : 0u));
+    else rd = camera_ray(C, in_frame ? px : 0u, in_frame ? py : 0u);
     RayCache rc;
     rc.slot = 0u;
     rc.trd = s_ray + threadIdx.x;
@@ -1338,6 +1356,26 @@ __global__ void __launch_bounds__(256) rt_raygen_kernel(const DevCamera C, float
     const f3 d = camera_ray(C, x, y);
     float *o = out + 3u * ((size_t)y * C.width + x);
     o[0] = d.x; o[1] = d.y; o[2] = d.z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rt_update_objects for a handful of objects: the new records travel as kernel arguments, so the update needs no staging
+// buffer and is ordered on the stream like a launch (the reference's update functions rewrite one or two objects per frame,
+// src/bin/scene1.rs:13-24, src/bin/scene4.rs:14-26).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kPatchObjects = 8u;
+struct PatchArgs {
+    uint32_t n;
+    uint32_t index[kPatchObjects];
+    DevObject object[kPatchObjects];
+};
+__global__ void __launch_bounds__(64) rt_patch_objects_kernel(DevObject *objects, const PatchArgs P) {
+    constexpr uint32_t kWords = sizeof(DevObject) / 4u;
+    for (uint32_t k = 0; k < P.n; k++) {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(objects + P.index[k]);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&P.object[k]);
+        for (uint32_t w = threadIdx.x; w < kWords; w += 64u) dst[w] = src[w];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

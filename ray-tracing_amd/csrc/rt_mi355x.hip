@@ -100,31 +100,24 @@ struct rt_ctx {
     DevBuf<uint32_t> rgba;
     DevBuf<float> accum;
     DevBuf<float> ray_dirs;   // Camera.ray_directions: 3 floats per pixel
+    // The table is filled lazily.  The first frame after a camera change computes its directions in the render kernel
+    // (a moving camera never pays for writing and re-reading 12 bytes per pixel); the second frame of an unchanged camera
+    // fills the table on its stream, and frames read it from then on, as the reference's frames do (src/renderer.rs:49).
+    bool dirs_valid = false;          // ray_dirs holds the directions of `camera`
+    uint32_t frames_this_camera = 0;  // renders since the last rt_set_camera
+    std::vector<std::pair<uint32_t, DevObject>> pending_objects;   // rt_update_objects records not yet on the device
     DevBuf<float4> wf_pool;       // ray pools of the re-grouping path tracer: wf_groups x kWfPool entries of 3.5 float4
     DevBuf<uint32_t> wf_ctrl;     // its tile counter
     uint32_t wf_groups = 0;       // persistent single-wave workgroups that fit the device (0: not queried yet)
+    uint32_t wf_chain_groups = 0; // the same for the kernel with per-pixel sample chains
     size_t n_bvh2_nodes = 0;      // nodes of the quantised two-child hierarchy of the current scene
-    uint64_t wf_order_key = 0;    // frame / row range the tile-row costs in wf_ctrl belong to
+    uint64_t wf_order_key[2] = {~0ull, ~0ull};   // scene / camera / row range the tile-row costs in wf_ctrl belong to
     uint32_t scene_serial = 0;    // bumped by rt_set_scene, rt_update_objects and rt_set_camera
     DevBuf<uint32_t> tile_sky;    // rt_tile_sky_kernel's word per workgroup of the launch described by tile_sky_key
     uint64_t tile_sky_key[2] = {~0ull, ~0ull};
     uint32_t tile_sky_words = 0, tile_sky_waves = 4;
-    hipStream_t tile_sky_stream = nullptr;   // stream of the launch that classified last
+    hipEvent_t tile_sky_done = nullptr;      // recorded behind the last classification kernel
     DevBuf<uint32_t> counters;
-    // rt_render_samples_device: the frame's tile rows are dealt to kBatchLanes interleaved shares, each with its own stream, pools,
-    // work counter and ray counters, so that launches of different shares overlap (see the entry point)
-    struct Lane {
-        hipStream_t stream = nullptr;
-        hipEvent_t done = nullptr;
-        DevBuf<float4> pool;
-        DevBuf<uint32_t> ctrl, counters;
-        uint64_t order_key = 0;
-        uint32_t last_blocks = 0;
-    };
-    static constexpr uint32_t kBatchLanes = 4;
-    Lane lanes[kBatchLanes];
-    hipEvent_t batch_in = nullptr;
-    uint32_t batch_lanes = 0;   // > 0: the last render was a sample batch over this many lanes (rt_get_stats sums their counters)
     uint32_t *static_counters = nullptr;       // this device's copy of the file-scope `scratch` array (rt_render_device_noalloc)
     const uint32_t *last_counters = nullptr;   // counter table the last render wrote
     std::vector<uint32_t> h_counters;
@@ -239,6 +232,16 @@ uint32_t march_leaf_slots(const rt_scene_desc *d, uint32_t i, int level) {
     }
 }
 
+// Camera::update ends with calculate_ray_directions (src/camera.rs:124): fills Camera.ray_directions for the current camera on
+// stream `s` (the caller has ordered `s` behind whatever still reads the table).
+hipError_t fill_ray_directions(rt_ctx *c, hipStream_t s) {
+    const DevCamera &C = c->camera;
+    hipLaunchKernelGGL(rt_raygen_kernel, dim3((C.width + 63u) / 64u, (C.height + 3u) / 4u), dim3(256), 0, s, C, c->ray_dirs.ptr);
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) c->dirs_valid = true;
+    return e;
+}
+
 // A render may have been launched on a caller's stream; anything that touches the same buffers from another
 // stream waits for it first.
 hipError_t wait_external(rt_ctx *c, hipStream_t next) {
@@ -327,18 +330,16 @@ int32_t rt_create(int32_t device_id, rt_ctx **out) {
 void rt_destroy(rt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    // every launch of this context -- on its own stream, on a caller's stream (which may no longer exist: it is never touched
+    // here) or on the share streams of a sample batch -- has drained before the first buffer goes
+    (void)hipDeviceSynchronize();
     for (const auto &r : c->pinned) (void)hipHostFree(r.first);
     c->objects.release(); c->materials.release(); c->lights.release(); c->sdfs.release(); c->textures.release();
     c->bvh_nodes.release(); c->unbounded.release(); c->bvh2_nodes.release(); c->bvh2_linear.release();
     for (auto &t : c->tex_data) t.release();
     c->rgba.release(); c->accum.release(); c->ray_dirs.release(); c->counters.release(); c->wf_pool.release(); c->wf_ctrl.release();
-    for (auto &l : c->lanes) {
-        if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
-        if (l.done) (void)hipEventDestroy(l.done);
-        l.pool.release(); l.ctrl.release(); l.counters.release();
-    }
-    if (c->batch_in) (void)hipEventDestroy(c->batch_in);
+    c->tile_sky.release();
+    if (c->tile_sky_done) (void)hipEventDestroy(c->tile_sky_done);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->evc0) (void)hipEventDestroy(c->evc0);
@@ -384,6 +385,7 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     // from here on the context's scene is being replaced: it counts as "not set" until every step below has succeeded, so a
     // failure in between can never leave a render launching on freed or half-updated buffers
     c->has_scene = false;
+    c->pending_objects.clear();
     std::vector<DevObject> objs(d->n_objects);
     for (uint32_t i = 0; i < d->n_objects; i++) objs[i] = make_dev_object(d->objects[i]);
     c->spheres_planes_only = d->n_objects > 0;
@@ -466,8 +468,21 @@ int32_t rt_update_objects(rt_ctx *c, uint32_t first, uint32_t count, const rt_ob
     std::vector<DevObject> objs(count);
     for (uint32_t i = 0; i < count; i++) objs[i] = make_dev_object(objects[i]);
     RT_HIP(c, hipSetDevice(c->device));
+    if (!c->scene.bvh_nodes && count <= 8u * kPatchObjects) {
+        // A few objects of a scene without hierarchy (what the reference's update functions do every frame): no waiting here.
+        // The records are handed to the next render launch, which patches the device array on its own stream first.
+        for (uint32_t i = 0; i < count; i++) {
+            bool found = false;
+            for (auto &pend : c->pending_objects) if (pend.first == first + i) { pend.second = objs[i]; found = true; }
+            if (!found) c->pending_objects.emplace_back(first + i, objs[i]);
+        }
+        std::copy(objects, objects + count, c->h_objects.begin() + first);
+        c->scene_serial += 1u;
+        return RT_OK;
+    }
     RT_HIP(c, wait_external(c, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->pending_objects.clear();   // (none: scenes with a hierarchy never queue)
     c->has_scene = false;   // set again once the device copy and the hierarchies are consistent
     RT_HIP(c, hipMemcpy(c->objects.ptr + first, objs.data(), (size_t)count * sizeof(DevObject), hipMemcpyHostToDevice));
     std::copy(objects, objects + count, c->h_objects.begin() + first);
@@ -504,6 +519,7 @@ int32_t rt_set_camera(rt_ctx *c, const rt_camera_desc *cam) {
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!cam || cam->width == 0 || cam->height == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad camera");
     if ((uint64_t)cam->width * cam->height > (1ull << 31)) return fail(c, RT_ERR_UNSUPPORTED, "frame above 2^31 pixels");
+    if (cam->width > 65535u || cam->height > 65535u) return fail(c, RT_ERR_UNSUPPORTED, "frame wider or higher than 65535 pixels");
     RT_HIP(c, hipSetDevice(c->device));
     c->has_camera = false;   // until the buffers and the direction table below are in place
     DevCamera &C = c->camera;
@@ -514,22 +530,24 @@ int32_t rt_set_camera(rt_ctx *c, const rt_camera_desc *cam) {
     C.iv = make_xform(cam->inverse_view);
     for (int k = 0; k < 3; k++) C.position[k] = cam->position[k];
     const size_t px = (size_t)cam->width * cam->height;
-    RT_HIP(c, wait_external(c, c->stream));
-    RT_HIP(c, hipStreamSynchronize(c->stream));   // a frame in flight still reads the previous table
     if (px != (size_t)C.width * C.height || !c->rgba.ptr) {
+        // a new frame size: the buffers are replaced, so everything in flight has to drain first
+        RT_HIP(c, hipDeviceSynchronize());
         RT_HIP(c, c->rgba.ensure(px));
         RT_HIP(c, c->accum.ensure(px * 4));
+        RT_HIP(c, c->ray_dirs.ensure(px * 3));
         RT_HIP(c, hipMemsetAsync(c->accum.ptr, 0, px * 4 * sizeof(float), c->stream));
+        RT_HIP(c, hipStreamSynchronize(c->stream));
     }
-    RT_HIP(c, c->ray_dirs.ensure(px * 3));
+    // Same size: nothing to wait for and nothing to launch.  Every render launch carries its own copy of the camera, and the
+    // direction table is rebuilt by a later frame on that frame's stream (see dirs_valid), ordered behind the frames that
+    // still read the old one.
     C.width = cam->width; C.height = cam->height;
     C.inv_w = 1.0f / (float)cam->width;
     C.inv_h = 1.0f / (float)cam->height;
     C.ray_dirs = c->ray_dirs.ptr;
-    // Camera::update ends with calculate_ray_directions (src/camera.rs:124): the table is rebuilt here, not per frame
-    hipLaunchKernelGGL(rt_raygen_kernel, dim3((cam->width + 63u) / 64u, (cam->height + 3u) / 4u), dim3(256), 0, c->stream, C, c->ray_dirs.ptr);
-    RT_HIP(c, hipGetLastError());
-    RT_HIP(c, hipStreamSynchronize(c->stream));   // renders may be launched on other streams
+    c->dirs_valid = false;
+    c->frames_this_camera = 0;
     c->scene_serial += 1u;
     c->has_camera = true;
     return RT_OK;
@@ -562,17 +580,26 @@ int32_t query_wf_groups(rt_ctx *c) {
     RT_HIP(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
     if (per_cu <= 0 || cus <= 0) return fail(c, RT_ERR_DEVICE, "occupancy query of the path tracing kernel failed");
     c->wf_groups = (uint32_t)per_cu * (uint32_t)cus;
+    RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_wf_chain_kernel, 64, 0));
+    if (per_cu <= 0) return fail(c, RT_ERR_DEVICE, "occupancy query of the path tracing kernel failed");
+    c->wf_chain_groups = (uint32_t)per_cu * (uint32_t)cus;
     return RT_OK;
 }
 
-// `lane`: one share of a sample batch -- the launch uses the lane's pools and counters, and the context's "last launch" state is
-// left to the caller.
-int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d_accum, void *stream, bool noalloc, rt_ctx::Lane *lane = nullptr) {
+#ifndef RT_WF_CHAIN_SINGLE
+#define RT_WF_CHAIN_SINGLE 0   // 1: single frames of large diffuse scenes also go through the kernel with sample chains (A/B builds)
+#endif
+// `samples` > 1: that many accumulating frames in one launch (large diffuse scenes only, see rt_render_samples_device).
+// `slot` of `slots`: the launch is one of several whose counter rows rt_get_stats sums afterwards (a sample batch rendered as
+// consecutive launches); every launch then writes its own block of rows.
+int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d_accum, void *stream, bool noalloc, uint32_t samples = 1u,
+                    uint32_t slot = 0u, uint32_t slots = 1u) {
     RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!p) return fail(c, RT_ERR_INVALID_ARGUMENT, "params is null");
     if (!c->has_scene || !c->has_camera) return fail(c, RT_ERR_STATE, "scene or camera not set");
     if (p->frame_index == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "frame_index must be >= 1");
+    if (p->flags & ~(uint32_t)RT_RENDER_ALL_FLAGS) return fail(c, RT_ERR_INVALID_ARGUMENT, "unknown bits in params.flags");
     uint32_t rb = p->row_begin, re = p->row_end;
     if (rb == 0 && re == 0) re = c->camera.height;
     if (re > c->camera.height || rb >= re) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad row range");
@@ -585,7 +612,16 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
     }
     RT_HIP(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    if (!lane) RT_HIP(c, wait_external(c, s));
+    RT_HIP(c, wait_external(c, s));
+    // objects changed by rt_update_objects since the last launch: patched on this stream, behind the frames that read the old ones
+    for (size_t i = 0; i < c->pending_objects.size(); i += kPatchObjects) {
+        PatchArgs P;
+        P.n = (uint32_t)std::min<size_t>(kPatchObjects, c->pending_objects.size() - i);
+        for (uint32_t k = 0; k < P.n; k++) { P.index[k] = c->pending_objects[i + k].first; P.object[k] = c->pending_objects[i + k].second; }
+        hipLaunchKernelGGL(rt_patch_objects_kernel, dim3(1), dim3(64), 0, s, c->objects.ptr, P);
+        RT_HIP(c, hipGetLastError());
+    }
+    c->pending_objects.clear();
 
     const DevScene &S = c->scene;
     const bool events = p->collect_events != 0;
@@ -612,20 +648,46 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         grid = dim3((tiles_x + kRfTiles - 1u) / kRfTiles, tiles_y);
         blocks = grid.x * grid.y;
     }
+    if (samples > 1u && !regroup) return fail(c, RT_ERR_STATE, "several samples per launch need the re-grouping path tracer");
+    const bool chain = regroup && (samples > 1u || RT_WF_CHAIN_SINGLE != 0);
     WfArgs W = {};
-    if (regroup) {
+    if (chain) {
+        { const int32_t r = query_wf_groups(c); if (r != RT_OK) return r; }
+        W.tiles_x = (c->camera.width + kChTileW - 1u) / kChTileW; W.tiles_y = tiles_y;
+        W.samples = samples;
+        // one wavefront per pool of pixel slots the launch can fill, at most as many as are resident at once
+        const uint64_t pools = ((uint64_t)W.tiles_x * W.tiles_y * kChTilePixels + kChPool - 1u) / kChPool;
+        grid = dim3((uint32_t)std::min<uint64_t>(c->wf_chain_groups, pools));
+        blocks = grid.x;
+        const size_t plane = (size_t)c->wf_chain_groups * kChPool;
+        RT_HIP(c, c->wf_pool.ensure(plane * 6u));   // six planes of 16 bytes per pool entry / pixel slot (the sixth half used)
+        RT_HIP(c, c->wf_ctrl.ensure((size_t)kWfCtrlRows + tiles_y));
+        c->wf_order_key[0] = c->wf_order_key[1] = ~0ull;   // the other kernel's per-row history in this buffer is gone
+        RT_HIP(c, hipMemsetAsync(c->wf_ctrl.ptr, 0, sizeof(uint32_t), s));   // the work counter
+        W.a = c->wf_pool.ptr; W.b = W.a + plane; W.c = W.b + plane; W.d = W.c + plane; W.e = W.d + plane;
+        W.g = reinterpret_cast<uint2 *>(W.e + plane);
+        W.ctrl = c->wf_ctrl.ptr;
+    } else if (regroup) {
         { const int32_t r = query_wf_groups(c); if (r != RT_OK) return r; }
         W.tiles_x = (c->camera.width + kWfTileW - 1u) / kWfTileW; W.tiles_y = tiles_y;
         grid = dim3(std::min<uint32_t>(c->wf_groups, W.tiles_x * W.tiles_y * 8u));   // at most eight items per tile
         blocks = grid.x;
-        DevBuf<float4> &pool = lane ? lane->pool : c->wf_pool;
-        DevBuf<uint32_t> &ctrl = lane ? lane->ctrl : c->wf_ctrl;
-        uint64_t &order_key = lane ? lane->order_key : c->wf_order_key;
+        DevBuf<float4> &pool = c->wf_pool;
+        DevBuf<uint32_t> &ctrl = c->wf_ctrl;
+        uint64_t *order_key = c->wf_order_key;
         RT_HIP(c, pool.ensure((size_t)c->wf_groups * kWfPool * 4u));   // four float4 planes per pool entry
-        RT_HIP(c, ctrl.ensure((size_t)kWfCtrlRows + tiles_y));
-        {   // the per-row costs only describe a launch over the same rows of the same frame
-            const uint64_t key = ((uint64_t)c->camera.width << 40) ^ ((uint64_t)c->camera.height << 20) ^ ((uint64_t)rb << 44) ^ ((uint64_t)re << 8) ^ stride ^ ((uint64_t)c->scene_serial << 52);
-            if (key != order_key) { RT_HIP(c, hipMemsetAsync(ctrl.ptr, 0, ((size_t)kWfCtrlRows + tiles_y) * sizeof(uint32_t), s)); order_key = key; }
+        {
+            const uint32_t *before = ctrl.ptr;
+            RT_HIP(c, ctrl.ensure((size_t)kWfCtrlRows + tiles_y));
+            if (ctrl.ptr != before) order_key[0] = order_key[1] = ~0ull;   // a new block holds no history
+        }
+        {   // the per-row costs only describe a launch over the same rows of the same frame (non-overlapping fields)
+            const uint64_t k0 = ((uint64_t)c->scene_serial << 32) | ((uint64_t)c->camera.width << 16) | (uint64_t)c->camera.height;
+            const uint64_t k1 = ((uint64_t)rb << 44) | ((uint64_t)re << 20) | (uint64_t)stride;   // stride <= 4096
+            if (k0 != order_key[0] || k1 != order_key[1]) {
+                RT_HIP(c, hipMemsetAsync(ctrl.ptr, 0, ((size_t)kWfCtrlRows + tiles_y) * sizeof(uint32_t), s));
+                order_key[0] = k0; order_key[1] = k1;
+            }
         }
         const size_t plane = (size_t)c->wf_groups * kWfPool;
         W.a = pool.ptr; W.b = W.a + plane; W.c = W.b + plane; W.d = W.c + plane;
@@ -638,10 +700,19 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
             return fail(c, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: the launch needs more than 2^20 counter words (workgroups x counters per workgroup)");
         counters = c->static_counters;
     } else {
-        DevBuf<uint32_t> &cb = lane ? lane->counters : c->counters;
-        RT_HIP(c, cb.ensure((size_t)blocks * ncnt));
-        counters = cb.ptr;
+        if (slot == 0u) RT_HIP(c, c->counters.ensure((size_t)blocks * ncnt * slots));   // the first launch of a batch sizes the table
+        counters = c->counters.ptr + (size_t)slot * blocks * ncnt;
     }
+
+    // primary directions: computed in the kernel by the first frame after a camera change (trace kernels on the linear scan
+    // and the march kernel can), read from the table otherwise
+    DevCamera cam = c->camera;
+    if (!c->dirs_valid) {
+        const bool can_inline = !regroup && !refill && !S.bvh_nodes;
+        if (can_inline && c->frames_this_camera == 0u) cam.ray_dirs = nullptr;
+        else RT_HIP(c, fill_ray_directions(c, s));
+    }
+    c->frames_this_camera += 1u;
 
     DevFrame F;
     F.frame_index = p->frame_index; F.row_begin = rb; F.row_end = re; F.tile_row_step = 8u * stride; F.leaf_slots = 0; F.accumulate = p->accumulate; F.seed = p->seed;
@@ -653,7 +724,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
     F.tile_sky = nullptr;
     // Sky tiles for the linear-scan trace kernels: classified once per (scene, camera, rows of the launch), on the launch's
     // stream ahead of the first render that needs them; every later launch over the same rows reuses the words.
-    const bool sky_tiles = !regroup && !refill && !S.ray_marching && !S.bvh_nodes && !c->has_refractive && !events && !noalloc && !lane && maxd >= 1u &&
+    const bool sky_tiles = !regroup && !refill && !S.ray_marching && !S.bvh_nodes && !c->has_refractive && !events && !noalloc && maxd >= 1u &&
                            S.n_objects >= 1u &&
                            !(p->flags & RT_RENDER_NO_SKY_TILES);
     if (sky_tiles) {
@@ -661,10 +732,12 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         const uint64_t k1 = ((uint64_t)rb << 44) | ((uint64_t)re << 20) | ((uint64_t)stride << 4) | (uint64_t)waves_per_block;   // stride <= 4096: 13 bits
         if (k0 != c->tile_sky_key[0] || k1 != c->tile_sky_key[1] || c->tile_sky_words != blocks) {
             RT_HIP(c, c->tile_sky.ensure(blocks));
-            hipLaunchKernelGGL(rt_tile_sky_kernel, dim3((4u * blocks + 255u) / 256u), dim3(256), 0, s, S, c->camera, F, grid.x, grid.y, waves_per_block,
+            hipLaunchKernelGGL(rt_tile_sky_kernel, dim3((4u * blocks + 255u) / 256u), dim3(256), 0, s, S, cam, F, grid.x, grid.y, waves_per_block,
                                reinterpret_cast<uint8_t *>(c->tile_sky.ptr));
             RT_HIP(c, hipGetLastError());
-            c->tile_sky_key[0] = k0; c->tile_sky_key[1] = k1; c->tile_sky_words = blocks; c->tile_sky_waves = waves_per_block; c->tile_sky_stream = s;
+            if (!c->tile_sky_done) RT_HIP(c, hipEventCreateWithFlags(&c->tile_sky_done, hipEventDisableTiming));
+            RT_HIP(c, hipEventRecord(c->tile_sky_done, s));
+            c->tile_sky_key[0] = k0; c->tile_sky_key[1] = k1; c->tile_sky_words = blocks; c->tile_sky_waves = waves_per_block;
         }
         F.tile_sky = c->tile_sky.ptr;
     }
@@ -678,9 +751,26 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
 #endif
 
     // the two timing events cost about 6 us per launch on the stream; callers that time their own stream opt out
-    const bool time_kernel = p->no_timing == 0 && !lane;
+    const bool time_kernel = p->no_timing == 0 && slots == 1u;
     if (time_kernel) RT_HIP(c, hipEventRecord(c->ev0, s));
-    if (regroup) {
+    if (chain) {
+#ifdef RT_WF_STATS
+        static unsigned long long *s_chstats = nullptr;
+        if (!s_chstats) (void)hipMalloc((void **)&s_chstats, 2 * WS_N * sizeof(unsigned long long));
+        (void)hipMemsetAsync(s_chstats, 0, 2 * WS_N * sizeof(unsigned long long), s);
+        W.stats = s_chstats;
+#endif
+        hipLaunchKernelGGL(rt_wf_chain_kernel, grid, dim3(64), 0, s, S, cam, F, W);
+#ifdef RT_WF_STATS
+        if (getenv("RT_WF_STATS_PRINT")) {
+            unsigned long long h[2 * WS_N];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h, s_chstats, sizeof(h), hipMemcpyDeviceToHost);
+            static const char *names[WS_N] = {"refill", "walk step", "leaf test", "finish", "shade batch", "prepare batch"};
+            for (int i = 0; i < WS_N; i++) fprintf(stderr, "WFSTAT %-14s runs %12llu lanes %14llu  mean lanes %5.1f\n", names[i], h[2 * i], h[2 * i + 1], h[2 * i] ? (double)h[2 * i + 1] / (double)h[2 * i] : 0.0);
+        }
+#endif
+    } else if (regroup) {
         hipLaunchKernelGGL(rt_wf_order_kernel, dim3(1), dim3(256), 0, s, W.ctrl, W.tiles_x, W.tiles_y, grid.x);
 #ifdef RT_WF_STATS
         static unsigned long long *s_wfstats = nullptr;
@@ -688,7 +778,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         (void)hipMemsetAsync(s_wfstats, 0, 2 * WS_N * sizeof(unsigned long long), s);
         W.stats = s_wfstats;
 #endif
-        hipLaunchKernelGGL(rt_wf_diffuse_kernel, grid, dim3(64), 0, s, S, c->camera, F, W);
+        hipLaunchKernelGGL(rt_wf_diffuse_kernel, grid, dim3(64), 0, s, S, cam, F, W);
 #ifdef RT_WF_STATS
         if (getenv("RT_WF_STATS_PRINT")) {
             unsigned long long h[2 * WS_N];
@@ -717,19 +807,19 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         }
 #endif
     } else if (refill) {
-        if (c->spheres_planes_only) launch(rt_refill_diffuse_kernel<true>, grid, 64u, 0, s, S, c->camera, F);
-        else launch(rt_refill_diffuse_kernel<false>, grid, 64u, 0, s, S, c->camera, F);
+        if (c->spheres_planes_only) launch(rt_refill_diffuse_kernel<true>, grid, 64u, 0, s, S, cam, F);
+        else launch(rt_refill_diffuse_kernel<false>, grid, 64u, 0, s, S, cam, F);
     } else if (S.ray_marching) {
         // up to 16 leaves (12.5 KiB of LDS per 64-thread workgroup) keep their object-space rays in LDS during the march loop
         const bool cache = c->leaf_slots >= 1u && c->leaf_slots <= (uint32_t)RT_MARCH_CACHE_MAX_SLOTS;
         F.leaf_slots = cache ? c->leaf_slots : 0u;
         const size_t lds = cache ? (size_t)c->leaf_slots * 3u * (threads + 1u) * sizeof(float) : 0u;
         if (cache) {
-            if (events) launch(rt_march_kernel<true, true>, grid, threads, lds, s, S, c->camera, F);
-            else launch(rt_march_kernel<false, true>, grid, threads, lds, s, S, c->camera, F);
+            if (events) launch(rt_march_kernel<true, true>, grid, threads, lds, s, S, cam, F);
+            else launch(rt_march_kernel<false, true>, grid, threads, lds, s, S, cam, F);
         } else {
-            if (events) launch(rt_march_kernel<true, false>, grid, threads, 0, s, S, c->camera, F);
-            else launch(rt_march_kernel<false, false>, grid, threads, 0, s, S, c->camera, F);
+            if (events) launch(rt_march_kernel<true, false>, grid, threads, 0, s, S, cam, F);
+            else launch(rt_march_kernel<false, false>, grid, threads, 0, s, S, cam, F);
         }
     } else {
         const size_t lds = (size_t)(maxd ? maxd : 1u) * 4u * threads * sizeof(float);
@@ -743,10 +833,10 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         const bool sp = c->spheres_planes_only && !events && !S.bvh_nodes;
         const int variant = (events ? 1 : 0) | (rsel << 1) | (S.bvh_nodes ? 8 : 0) | (sp ? 16 : 0);
         switch (variant) {
-#define RT_CASE(V, E, R, D, B) case V: launch(rt_trace_kernel<E, R, D, B>, grid, threads, lds, s, S, c->camera, F); break;
-            case 16: launch(rt_trace_kernel<false, false, 1, false, true>, grid, threads, lds, s, S, c->camera, F); break;
-            case 18: launch(rt_trace_kernel<false, true, 8, false, true>, grid, threads, lds, s, S, c->camera, F); break;
-            case 20: launch(rt_trace_kernel<false, true, 32, false, true>, grid, threads, lds, s, S, c->camera, F); break;
+#define RT_CASE(V, E, R, D, B) case V: launch(rt_trace_kernel<E, R, D, B>, grid, threads, lds, s, S, cam, F); break;
+            case 16: launch(rt_trace_kernel<false, false, 1, false, true>, grid, threads, lds, s, S, cam, F); break;
+            case 18: launch(rt_trace_kernel<false, true, 8, false, true>, grid, threads, lds, s, S, cam, F); break;
+            case 20: launch(rt_trace_kernel<false, true, 32, false, true>, grid, threads, lds, s, S, cam, F); break;
             RT_CASE(0, false, false, 1, false) RT_CASE(1, true, false, 1, false)
             RT_CASE(2, false, true, 8, false) RT_CASE(3, true, true, 8, false)
             RT_CASE(4, false, true, 32, false) RT_CASE(5, true, true, 32, false)
@@ -759,11 +849,9 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
     }
     RT_HIP(c, hipGetLastError());
     if (time_kernel) RT_HIP(c, hipEventRecord(c->ev1, s));
-    if (lane) { lane->last_blocks = blocks; c->frames += 1; return RT_OK; }
     c->kernel_timed = time_kernel;
-    c->last_blocks = blocks; c->last_ncnt = ncnt; c->last_events = events; c->timed = true; c->last_stream = s;
-    c->last_counters = counters;
-    c->batch_lanes = 0;
+    c->last_blocks = blocks * (slot + 1u); c->last_ncnt = ncnt; c->last_events = events; c->timed = true; c->last_stream = s;
+    c->last_counters = noalloc ? counters : c->counters.ptr;
 #ifdef RT_DIAG
     if (getenv("RT_DIAG_PRINT")) {
         std::vector<unsigned long long> all((size_t)n_waves * DG_N);
@@ -775,7 +863,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         for (int i = 0; i < DG_N; i++) fprintf(stderr, "DIAG %-24s %14llu wave-cycles %6.2f%%  (%.0f per wave)\n", names[i], h[i], 100.0 * (double)h[i] / (double)(h[0] ? h[0] : 1), (double)h[i] / (double)n_waves);
     }
 #endif
-    c->frames += 1;
+    c->frames += samples;
     return RT_OK;
     RT_GUARD_END(c)
 }
@@ -793,12 +881,9 @@ int32_t rt_render_device_noalloc(rt_ctx *c, const rt_render_params *p, void *d_r
 }
 
 // sample_count accumulating frames, frame_index = p->frame_index ... + sample_count - 1: the same pixels as that many
-// rt_render_device calls.  Scenes that go through the re-grouping path tracer are rendered as kBatchLanes interleaved shares
-// of the tile rows, every share on a stream of its own with its own pools: the launches of one share run in order (a pixel's
-// samples are accumulated by consecutive launches of ONE stream, in frame_index order), launches of different shares
-// touch different rows and overlap, so the end of one launch -- a few wavefronts finishing the last tiles -- is filled by the
-// start of another (8K / 10 000 spheres / 64 spp: 318 -> 299...307 ms depending on which hardware queues the runtime gives the
-// four streams; two shares 308, three 322).  The caller's stream waits for all shares at the end.
+// rt_render_device calls.  Scenes that go through the re-grouping path tracer are rendered by ONE launch in which every
+// pixel's samples are traced one after the other by the wavefront that holds the pixel (rt_wf_chain_kernel): the accumulator
+// is read and written once per call instead of once per sample.  Other scenes: one launch per sample on the caller's stream.
 int32_t rt_render_samples_device(rt_ctx *c, const rt_render_params *p, uint32_t sample_count, void *d_rgba8, void *d_accum, void *stream) {
     RT_GUARD_BEGIN
     if (!c) return RT_ERR_INVALID_ARGUMENT;
@@ -808,66 +893,18 @@ int32_t rt_render_samples_device(rt_ctx *c, const rt_render_params *p, uint32_t 
     if (p->collect_events) return fail(c, RT_ERR_INVALID_ARGUMENT, "rt_render_samples_device does not count events");
     if (p->frame_index == 0 || p->frame_index > 0xFFFFFFFFu - sample_count) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad frame_index range");
     if (!c->has_scene || !c->has_camera) return fail(c, RT_ERR_STATE, "scene or camera not set");
-    uint32_t rb = p->row_begin, re = p->row_end;
-    if (rb == 0 && re == 0) re = c->camera.height;
-    if (re > c->camera.height || rb >= re) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad row range");
-    const uint32_t stride = p->tile_row_stride ? p->tile_row_stride : 1u;
     const DevScene &S = c->scene;
     const bool regroup = !S.ray_marching && S.bvh2_nodes && S.diffuse && !c->has_refractive && S.max_ray_bounces >= 1u &&
                          !(p->flags & RT_RENDER_ONE_LANE_PER_PIXEL);
-    const uint32_t tile_rows = ((re - rb + 7u) / 8u + stride - 1u) / stride;
-    constexpr uint32_t L = rt_ctx::kBatchLanes;
-    RT_HIP(c, hipSetDevice(c->device));
-    bool shares = regroup && sample_count >= 2u && (rb % 8u) == 0u && stride * L <= 4096u;
-    if (shares) {
-        // a share must still keep every wavefront busy for a while: at least six tiles per resident wavefront in the whole
-        // launch (8K: 7.9; at 4K, 2.0, four shares measured 22 % slower than consecutive launches)
-        const int32_t r = query_wf_groups(c);
-        if (r != RT_OK) return r;
-        const uint64_t tiles = (uint64_t)((c->camera.width + kWfTileW - 1u) / kWfTileW) * tile_rows;
-        shares = tiles >= 6ull * c->wf_groups || (p->flags & RT_RENDER_SAMPLE_SHARES);
-    }
-    if (!shares) {
-        // one launch after the other on the caller's stream
-        rt_render_params q = *p;
-        for (uint32_t i = 0; i < sample_count; i++) {
-            q.frame_index = p->frame_index + i;
-            const int32_t r = render_impl(c, &q, d_rgba8, d_accum, stream, false);
-            if (r != RT_OK) return r;
-        }
-        return RT_OK;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    RT_HIP(c, wait_external(c, s));
-    if (!c->batch_in) RT_HIP(c, hipEventCreateWithFlags(&c->batch_in, hipEventDisableTiming));
-    for (auto &l : c->lanes) {
-        if (!l.stream) RT_HIP(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-        if (!l.done) RT_HIP(c, hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
-    }
-    // the shares start after whatever the caller queued before this call (an accumulator reset, an upload)
-    RT_HIP(c, hipEventRecord(c->batch_in, s));
-    for (auto &l : c->lanes) RT_HIP(c, hipStreamWaitEvent(l.stream, c->batch_in, 0));
+    if (regroup) return render_impl(c, p, d_rgba8, d_accum, stream, false, sample_count);
+    // one launch after the other on the caller's stream, each with its own block of counter rows
     rt_render_params q = *p;
     q.no_timing = 1;
-    q.row_end = re;
-    q.tile_row_stride = stride * L;
-    int32_t status = RT_OK;
-    for (uint32_t i = 0; i < sample_count && status == RT_OK; i++) {
+    for (uint32_t i = 0; i < sample_count; i++) {
         q.frame_index = p->frame_index + i;
-        for (uint32_t k = 0; k < L && status == RT_OK; k++) {
-            q.row_begin = rb + 8u * stride * k;   // share k: tile rows k, k + L, k + 2 L, ... of the caller's rows
-            if (q.row_begin >= re) { c->lanes[k].last_blocks = 0u; continue; }   // fewer tile rows than shares
-            status = render_impl(c, &q, d_rgba8, d_accum, c->lanes[k].stream, false, &c->lanes[k]);
-        }
+        const int32_t r = render_impl(c, &q, d_rgba8, d_accum, stream, false, 1u, i, sample_count);
+        if (r != RT_OK) return r;
     }
-    // whatever happened, the caller's stream continues only after every share has drained
-    for (auto &l : c->lanes) {
-        if (hipEventRecord(l.done, l.stream) == hipSuccess) (void)hipStreamWaitEvent(s, l.done, 0);
-        else (void)hipStreamSynchronize(l.stream);
-    }
-    if (status != RT_OK) return status;
-    c->kernel_timed = false; c->last_events = false; c->last_ncnt = 1u; c->timed = true; c->last_stream = s;
-    c->batch_lanes = L;
     return RT_OK;
     RT_GUARD_END(c)
 }
@@ -961,6 +998,9 @@ int32_t rt_read_ray_directions(rt_ctx *c, float *out, size_t n_vec3) {
     if (!c->has_camera) return fail(c, RT_ERR_STATE, "camera not set");
     if (!out || n_vec3 != (size_t)c->camera.width * c->camera.height) return fail(c, RT_ERR_INVALID_ARGUMENT, "out must hold width*height directions");
     RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, wait_external(c, c->stream));
+    if (!c->dirs_valid) RT_HIP(c, fill_ray_directions(c, c->stream));   // no frame has needed the table since the camera changed
+    RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, hipMemcpy(out, c->ray_dirs.ptr, n_vec3 * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return RT_OK;
     RT_GUARD_END(c)
@@ -1010,23 +1050,14 @@ int32_t rt_get_stats(rt_ctx *c, rt_stats *out) {
         RT_HIP(c, hipStreamSynchronize(c->last_stream));
         float ms = 0.0f;
         if (c->kernel_timed && hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) out->last_kernel_ms = ms;
-        if (c->batch_lanes) {
-            // a sample batch: rays of its last sample, summed over the shares (every launch overwrites its share's counters)
-            for (uint32_t k = 0; k < c->batch_lanes; k++) {
-                const rt_ctx::Lane &l = c->lanes[k];
-                c->h_counters.resize(l.last_blocks);
-                RT_HIP(c, hipMemcpy(c->h_counters.data(), l.counters.ptr, (size_t)l.last_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost));
-                for (uint32_t b = 0; b < l.last_blocks; b++) out->rays_total += c->h_counters[b];
-            }
-        } else {
-            const size_t n = (size_t)c->last_blocks * c->last_ncnt;
-            c->h_counters.resize(n);
-            RT_HIP(c, hipMemcpy(c->h_counters.data(), c->last_counters, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            for (uint32_t b = 0; b < c->last_blocks; b++) {
-                const uint32_t *row = c->h_counters.data() + (size_t)b * c->last_ncnt;
-                out->rays_total += row[0];
-                if (c->last_events) for (uint32_t i = 0; i < (uint32_t)RT_CNT_COUNT; i++) out->counters[i] += row[1 + i];
-            }
+        const size_t n = (size_t)c->last_blocks * c->last_ncnt;
+        c->h_counters.resize(n);
+        RT_HIP(c, hipMemcpy(c->h_counters.data(), c->last_counters, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t b = 0; b < c->last_blocks; b++) {
+            const uint32_t *row = c->h_counters.data() + (size_t)b * c->last_ncnt;
+            out->rays_total += row[0] & 0x7FFFFFFFu;
+            if (row[0] & 0x80000000u) out->rays_sky_tiles += row[0] & 0x7FFFFFFFu;   // a workgroup of nothing but sky tiles
+            if (c->last_events) for (uint32_t i = 0; i < (uint32_t)RT_CNT_COUNT; i++) out->counters[i] += row[1 + i];
         }
     }
     out->last_copy_ms = c->last_copy_ms;
@@ -1049,7 +1080,7 @@ int32_t rt_get_hierarchy_info(rt_ctx *c, rt_hierarchy_info *out) {
     out->regrouping_kernel = (!S.ray_marching && S.bvh2_nodes && S.diffuse && !c->has_refractive && S.max_ray_bounces >= 1u) ? 1u : 0u;
     if (c->tile_sky_words != 0u && c->tile_sky_key[0] != ~0ull) {
         RT_HIP(c, hipSetDevice(c->device));
-        RT_HIP(c, hipStreamSynchronize(c->tile_sky_stream));
+        RT_HIP(c, hipEventSynchronize(c->tile_sky_done));
         std::vector<uint32_t> words(c->tile_sky_words);
         RT_HIP(c, hipMemcpy(words.data(), c->tile_sky.ptr, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         const uint32_t all = 0x01010101u >> (8u * (4u - c->tile_sky_waves));

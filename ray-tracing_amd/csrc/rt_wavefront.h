@@ -75,6 +75,10 @@ struct WfArgs {
     uint32_t *ctrl;   // kWfCtrl* header words, then [kWfCtrlRows + r] = rays traced in tile row r
     uint32_t tiles_x, tiles_y;
     unsigned long long *stats;   // diagnostic builds only
+    // rt_wf_chain_kernel only
+    float4 *e;        // per pixel slot: the pixel's accumulator entry so far (Renderer.accumulated[pos] plus the samples added)
+    uint2 *g;         //                 pixel index, samples of this launch already added
+    uint32_t samples; // accumulating frames this launch renders: frame_index = F.frame_index ... F.frame_index + samples - 1
 };
 
 // pixel of pool slot j in stage 0: sub-tile j / 64, lane-in-tile j % 64 as in lane_pixel
@@ -380,6 +384,188 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_diffuse_kernel(const De
         const unsigned long long t1 = wall_clock64();
         pa[0] = make_float4(__uint_as_float((uint32_t)ws_t0), __uint_as_float((uint32_t)(ws_t0 >> 32)), __uint_as_float((uint32_t)t1), __uint_as_float((uint32_t)(t1 >> 32)));
     }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same path tracer with per-pixel sample chains: ONE launch renders W.samples accumulating frames
+// (frame_index = F.frame_index ... F.frame_index + samples - 1), the pixels of that many launches of the kernel above.
+//
+// A wavefront's pool entries no longer belong to one tile and one bounce.  Every entry is the current path of a PIXEL SLOT:
+// when a path ends (miss, or depth limit) its value is added to the slot's copy of the pixel's accumulator entry and the entry
+// continues with the SAME pixel's next sample; when the pixel has had all its samples, its accumulator entry and RGBA8 value
+// are written -- once per launch instead of once per sample -- and the slot takes the next pixel of the launch (tiles of 64x8
+// pixels from one counter, pixel by pixel).  A pixel's samples are therefore traced one after the other and added in
+// frame_index order, exactly the order of `self.accumulated[pos] += p` over consecutive frames (src/renderer.rs:59-66), and
+// the random numbers are keyed by (seed, pixel, frame_index, bounce), so every path does the arithmetic it does in the
+// kernels above: accumulator and frame are bit-identical to `samples` launches of them.
+// What it buys: the pool stays full from the first round to the end of the launch whatever the lengths of the paths (no
+// drain per bounce and per tile, every trace pass runs over a full pool of rays at mixed depths), no launch tail and no
+// order kernel per sample, and 36 bytes of frame traffic per pixel and LAUNCH instead of per sample.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kChTileW = 64u, kChTilePixels = kChTileW * 8u;   // work item: 64x8 pixels = eight 8x8 blocks side by side
+// Pixel slots (= pool entries) per wavefront.  The pool never drains here, so it can be smaller than the other kernel's, and
+// it has to be: every entry is rewritten and re-read each round, and the pools of all resident wavefronts together should
+// stay inside the 256 MB last-level cache (measured at 8K / 64 spp: 512 slots 395 ms, 256 slots 300 ms, 128 slots 310 ms).
+#ifndef RT_CH_POOL
+#define RT_CH_POOL 256
+#endif
+constexpr uint32_t kChPool = RT_CH_POOL;
+
+struct WfCursor { uint32_t x0, y0, i, n, exhausted; };   // wave-uniform: the item this wavefront is handing out, pixel by pixel
+
+// Gives the next pixel of the launch to every lane that asks for one (`want`); false: the launch has no pixels left.
+RT_DEV bool wf_claim_pixel(const DevCamera &C, const DevFrame &F, const WfArgs &W, WfCursor &cur, bool want, uint32_t &pos) {
+    bool got = false;
+    const uint32_t n_items = W.tiles_x * W.tiles_y;
+    for (;;) {
+        const uint64_t m = __ballot(want && !got);
+        if (m == 0ull) break;
+        if (cur.i >= cur.n) {
+            if (cur.exhausted != 0u) break;
+            uint32_t item = 0u;
+            if (threadIdx.x == 0u) item = atomicAdd(&W.ctrl[kWfCtrlNext], 1u);
+            item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+            if (item >= n_items) { cur.exhausted = 1u; break; }
+            const uint32_t trow = item / W.tiles_x, tx = item - trow * W.tiles_x;   // tile rows top-down
+            cur.x0 = tx * kChTileW; cur.y0 = F.row_begin + trow * F.tile_row_step; cur.i = 0u; cur.n = kChTilePixels;
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const uint32_t avail = cur.n - cur.i, asked = (uint32_t)__popcll(m);
+        // a pixel of the item that lies outside the frame is nobody's: the lane asks again
+        if (want && !got && rank < avail) got = wf_slot_pixel(C, F, cur.x0, cur.y0, cur.i + rank, pos);
+        cur.i += asked < avail ? asked : avail;
+    }
+    return got;
+}
+
+__global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_chain_kernel(const DevScene S, const DevCamera C, const DevFrame F, const WfArgs W) {
+    __shared__ uint32_t s_stack[kWfStack * 64u];
+    const uint32_t lane = threadIdx.x;
+    const size_t slice = (size_t)blockIdx.x * kChPool;
+    float4 *pa = W.a + slice, *pb = W.b + slice, *pc = W.c + slice, *pd = W.d + slice, *pe = W.e + slice;
+    uint2 *pg = W.g + slice;
+    const uint32_t maxd = S.max_ray_bounces, n_samples = W.samples;
+    const f3 ambient = ld3(S.ambient);
+    const bool jitter = S.enable_accumulation != 0u;
+    uint32_t rays = 0u;
+    Cnt<false> nocnt;
+#ifdef RT_WF_STATS
+    __shared__ uint32_t s_stat[2 * WS_N];
+    if (lane < 2u * WS_N) s_stat[lane] = 0u;
+    __syncthreads();
+#endif
+    WfCursor cur = {0u, 0u, 0u, 0u, 0u};
+    uint32_t n = 0u;    // paths in the pool
+    bool boot = true;   // first pass: every pixel slot is empty and takes its first pixel
+    for (;;) {
+        if (!boot) {
+            if (n == 0u) break;
+            wf_trace_pool(S, C, F, false, n, 0u, 0u, pa, pb, pd, s_stack, rays WS_PASS);
+            __syncthreads();
+        }
+        // ---- shade: color_diffuse at every hit / miss of this round (ray_tracing.rs:87-114, :155-157), each path at its own depth
+        const uint32_t n_in = boot ? kChPool : n;
+        uint32_t out = 0u;
+        for (uint32_t base = 0u; base < n_in; base += 64u) {
+            const uint32_t j = base + lane;
+            const bool alive = j < n_in;
+            WS_ADD(WS_SHADE, __ballot(alive));
+            uint32_t q = j, depth = 0u, key = 0u;
+            bool goes_on = false, ended = false;
+            f3 no = splat3(0.0f), nd = splat3(0.0f), p = splat3(0.0f), cc = splat3(1.0f), V = splat3(0.0f);
+            if (!boot && alive) {
+                const float4 A = pa[j], B = pb[j], Cv = pc[j], D = pd[j];
+                const f3 ro = mk3(A.x, A.y, A.z), rd = mk3(B.x, B.y, B.z), L = mk3(Cv.x, Cv.y, Cv.z), Cc = mk3(Cv.w, D.x, D.y);
+                key = __float_as_uint(A.w);
+                q = __float_as_uint(B.w) & 0xFFFFu; depth = __float_as_uint(B.w) >> 16;
+                const uint32_t hobj = __float_as_uint(D.w);
+                if (hobj == kWfHitMiss) {
+                    V = L + ambient * Cc;
+                    ended = true;
+                } else {
+                    const int obj = (int)(hobj & 0x0FFFFFFFu), sub = (int)(hobj >> 30);
+                    HitRec h; Mtl m;
+                    h.u = 0.0f; h.v = 0.0f;
+                    const DevObject &o = S.objects[obj];
+                    finalize_one<false>(o, S.materials[o.material], ro, rd, D.z, sub, h, m, nocnt);
+                    f3 albedo = m.albedo;
+                    if (m.texture >= 0) albedo = tex_from_uv(S.textures[m.texture], h.u, h.v);
+                    p = L + m.emission_power * albedo;
+                    if (depth + 1u >= maxd) {   // the child at the depth limit returns its light_color (:83-85)
+                        V = p;
+                        ended = true;
+                    } else {
+                        rt_reflection_ray(rd, h, m.roughness, key, true, jitter, no, nd);
+                        cc = Cc * albedo;
+                        key = rt_rng_child_key(key, 0u);
+                        depth += 1u;
+                        goes_on = true;
+                    }
+                }
+            }
+            // ---- a path that ended: its value joins the pixel's accumulator entry; the pixel goes on with its next sample or is written
+            uint32_t pos = 0u, sample = 0u;
+            bool respawn = false, need_pixel = boot && alive;
+            if (ended) {
+                const uint2 G = pg[q];
+                pos = G.x; sample = G.y + 1u;
+                if (F.accumulate) {
+                    float4 E = pe[q];
+                    E.x = E.x + V.x; E.y = E.y + V.y; E.z = E.z + V.z; E.w = E.w + 1.0f;   // src/renderer.rs:60
+                    if (sample < n_samples) pe[q] = E;
+                    else store_summed(F, pos, E, F.frame_index + n_samples - 1u);
+                } else if (sample >= n_samples) {
+                    store_pixel(F, pos, V);
+                }
+                if (sample < n_samples) { pg[q] = make_uint2(pos, sample); respawn = true; }
+                else need_pixel = true;
+            }
+            // ---- empty pixel slots take the launch's next pixels
+            if (__ballot(need_pixel) != 0ull) {
+                uint32_t npos = 0u;
+                const bool got = wf_claim_pixel(C, F, W, cur, need_pixel, npos);
+                if (need_pixel && got) {
+                    pos = npos; sample = 0u;
+                    pe[q] = load_accum(F, pos);
+                    pg[q] = make_uint2(pos, 0u);
+                    respawn = true;
+                }
+            }
+            if (respawn) {   // camera ray of this pixel's next frame (src/renderer.rs:49-57; RayTracing::albedo seeds light 0, contribution 1)
+                no = ld3(C.position); nd = ld3(C.ray_dirs + 3u * (size_t)pos);
+                p = splat3(0.0f); cc = splat3(1.0f);
+                key = rt_rng_path_key(F.seed, pos, F.frame_index + sample);
+                depth = 0u;
+                goes_on = true;
+            }
+            // the next ray against the linear objects (wave-uniform loop: kept outside the divergent code above)
+            float nclosest = RT_F32_MAX;
+            int nbest = -1, nbest_sub = 0;
+            if (S.n_bvh2_linear != 0u && __ballot(goes_on) != 0ull) {
+                if (goes_on) wf_linear_objects(S, no, nd, nclosest, nbest, nbest_sub);
+            }
+            // every lane has read its entry: the compacted writes below never reach an entry that is still unread
+            const uint64_t on = __ballot(goes_on);
+            if (goes_on) {
+                const uint32_t k = out + __builtin_amdgcn_mbcnt_hi((uint32_t)(on >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)on, 0u));
+                pa[k] = make_float4(no.x, no.y, no.z, __uint_as_float(key));
+                pb[k] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(q | (depth << 16)));
+                pc[k] = make_float4(p.x, p.y, p.z, cc.x);
+                pd[k] = make_float4(cc.y, cc.z, nclosest, __uint_as_float(wf_pack_hit(nbest, nbest_sub)));
+            }
+            out += (uint32_t)__popcll(on);
+        }
+        __syncthreads();   // pool writes of all lanes before the next round reads them
+        n = out;
+        boot = false;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_xor(rays, off, 64);
+    if (lane == 0u) F.counters[blockIdx.x] = rays;
+#ifdef RT_WF_STATS
+    __syncthreads();
+    if (lane < 2u * WS_N && W.stats) atomicAdd(&W.stats[lane], (unsigned long long)s_stat[lane]);
 #endif
 }
 

@@ -504,6 +504,72 @@ def test_full_size_4k_properties(pkg, orc, ctx, name):
         assert_parity(rgba[row:row + 1], ref["rgba"][row:row + 1], a[row:row + 1], ref["accum"][row:row + 1], what=f"{name} 4K row {row}")
 
 
+@pytest.mark.parametrize("name", ["scene3", "tex4"])
+def test_bench_configuration_at_4k_equals_the_unclassified_frame(pkg, orc, ctx, name):
+    """The exact configuration bench.py times -- 3840x2160, tile classification on, RT_RENDER_SKIP_ACCUM_STORE -- against the
+    same library without the classification (whole frame, bytes and ray counts), and against the oracle on the tile rows
+    where the frame changes between sky and ground: the first and last 8-row bands that hold a pixel different from a miss,
+    and the bands next to them."""
+    import torch
+    s = pkg.Scene(name)
+    s.desc.max_ray_bounces = 5
+    w, h = 3840, 2160
+    ctx.load(s, w, h)
+    frames = {}
+    for flags in (pkg.RT_RENDER_SKIP_ACCUM_STORE, pkg.RT_RENDER_SKIP_ACCUM_STORE | pkg.RT_RENDER_NO_SKY_TILES, 0):
+        rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        for _ in range(2):   # the first frame of a camera computes its directions in the kernel, the second reads the table
+            ctx.render_device(frame_index=1, d_rgba8=rgba.data_ptr(), flags=flags, no_timing=True)
+        st = ctx.stats()
+        frames[flags] = (rgba.cpu().numpy(), st["rays_total"], st["rays_sky_tiles"])
+    bench, plain, stored = (frames[k] for k in (pkg.RT_RENDER_SKIP_ACCUM_STORE, pkg.RT_RENDER_SKIP_ACCUM_STORE | pkg.RT_RENDER_NO_SKY_TILES, 0))
+    assert np.array_equal(bench[0], plain[0]) and np.array_equal(bench[0], stored[0]), "the classified 4K frame differs from the traced one"
+    assert bench[1] == plain[1] == stored[1] and plain[2] == 0 and 0 < bench[2] < bench[1]
+    info = ctx.hierarchy_info()
+    assert info["sky_workgroups"] * 256 == bench[2], "every pixel of a sky workgroup counts as one camera ray"
+    miss = bench[0][0, 0]
+    band_has_object = (bench[0].reshape(h // 8, 8, w, 4) != miss).any(axis=(1, 2, 3))
+    first, last = np.flatnonzero(band_has_object)[[0, -1]]
+    cam = s.camera(w, h)
+    for band in sorted({max(first - 1, 0), first, first + 1, last - 1, last, min(last + 1, h // 8 - 1)}):
+        ref = orc.render(s.desc, cam, s.textures(), rows=(8 * band, 8 * band + 8), n_threads=16)
+        assert np.array_equal(bench[0][8 * band:8 * band + 8], ref["rgba"][8 * band:8 * band + 8]), f"{name} 4K tile row {band}"
+
+
+@pytest.mark.parametrize("name,size", [("scene3", (333, 77)), ("scene1", (800, 600)), ("tex4", (257, 131)), ("scene4", (320, 240)), ("scene3", (3840, 2160))])
+def test_first_frame_of_a_camera_equals_the_frames_that_read_the_table(pkg, orc, ctx, name, size):
+    """rt_set_camera launches nothing: the first frame after it computes its primary directions in the render kernel, the
+    second fills Camera.ray_directions on its stream and later frames read it.  All three are the same frame, for a sequence
+    of camera poses set back to back (a moving camera) and with and without the tile classification."""
+    s = pkg.Scene(name)
+    w, h = size
+    ctx.load(s, w, h)
+    poses = [None, ((0.2, 1.9, 4.6), (0.05, -0.1, -1.0)), ((-0.4, 2.4, 5.2), (-0.1, -0.25, -1.0))]
+    for k, pose in enumerate(poses):
+        cam = s.camera(w, h) if pose is None else pkg.make_camera(pose[0], pose[1], w, h)
+        ctx.set_camera(cam)
+        got = []
+        for f in range(3):
+            ctx.render_device(frame_index=1, flags=pkg.RT_RENDER_NO_SKY_TILES if f == 2 else 0)
+            got.append((ctx.read_accum().copy(), ctx.stats()["rays_total"]))
+        assert got[0][1] == got[1][1] == got[2][1]
+        assert np.array_equal(got[0][0].view(np.uint32), got[1][0].view(np.uint32)), f"pose {k}: in-kernel directions differ from the table's"
+        assert np.array_equal(got[0][0].view(np.uint32), got[2][0].view(np.uint32))
+        if w * h <= 800 * 600:
+            ref = orc.render(s.desc, cam, s.textures(), n_threads=16)
+            assert np.array_equal(got[0][0].view(np.uint32), ref["accum"].view(np.uint32)), f"pose {k} differs from the oracle"
+        dirs = ctx.read_ray_directions()
+        assert np.array_equal(dirs.view(np.uint32), orc.ray_directions(cam).reshape(h, w, 3).view(np.uint32))
+    # a pose that is replaced before any frame was rendered leaves nothing behind
+    ctx.set_camera(pkg.make_camera((5.0, 5.0, 5.0), (0.0, 0.0, 1.0), w, h))
+    cam = s.camera(w, h)
+    ctx.set_camera(cam)
+    ctx.render_device(frame_index=1)
+    a = ctx.read_accum().copy()
+    ctx.render_device(frame_index=1)
+    assert np.array_equal(a.view(np.uint32), ctx.read_accum().view(np.uint32))
+
+
 def _counters_without_candidate_tests(pkg, d):
     skip = {"test_sphere", "test_triangle", "test_cuboid", "test_plane", "test_cylinder", "test_cone", "bvh_node"}
     return {k: d[k] for k in pkg.COUNTER_NAMES if k not in skip}
@@ -580,12 +646,14 @@ def test_sample_batch_equals_consecutive_renders(pkg, ctx, name, size, samples):
     def run(batched, rows=None, stride=0, first=1, n=samples, accum=None, rgba=None, stream=None):
         if batched:
             ctx.render_samples_device(first, n, seed=77, rows=rows, tile_row_stride=stride, d_rgba8=rgba.data_ptr() if rgba is not None else 0,
-                                      d_accum=accum.data_ptr() if accum is not None else 0, stream=stream, flags=pkg.RT_RENDER_SAMPLE_SHARES)
-        else:
-            for f in range(first, first + n):
-                ctx.render_device(frame_index=f, accumulate=True, seed=77, rows=rows, tile_row_stride=stride, d_rgba8=rgba.data_ptr() if rgba is not None else 0,
-                                  d_accum=accum.data_ptr() if accum is not None else 0, stream=stream)
-        return ctx.stats()["rays_total"]
+                                      d_accum=accum.data_ptr() if accum is not None else 0, stream=stream)
+            return ctx.stats()["rays_total"]   # of the whole call
+        total = 0
+        for f in range(first, first + n):
+            ctx.render_device(frame_index=f, accumulate=True, seed=77, rows=rows, tile_row_stride=stride, d_rgba8=rgba.data_ptr() if rgba is not None else 0,
+                              d_accum=accum.data_ptr() if accum is not None else 0, stream=stream)
+            total += ctx.stats()["rays_total"]
+        return total
 
     # the context's own buffers and stream
     got = {}

@@ -19,7 +19,7 @@ def test_abi_library_exports_every_declared_symbol(pkg):
     l = pkg.lib()
     for name in declared:
         assert hasattr(l, name), f"librt_mi355x.so does not export {name}"
-    assert l.rt_abi_version() == 2
+    assert l.rt_abi_version() == 3
 
 
 def test_no_gpu_calls_fail_loudly_instead_of_falling_back(pkg):
