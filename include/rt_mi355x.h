@@ -287,8 +287,10 @@ int32_t rt_free_host_frame(rt_ctx *ctx, void *ptr);
  * returns after the launch; the context's other calls wait for it before touching its buffers. */
 int32_t rt_render_device(rt_ctx *ctx, const rt_render_params *params, void *d_rgba8, void *d_accum, void *stream);
 
-/* rt_render_device for callers that cannot allocate device memory while they render (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same frame, same arguments; the
+/* rt_render_device for callers that cannot allocate device memory while they render (tight serving loops, harnesses that
+ * forbid hipMalloc, code under stream capture -- there only with no_timing set and on the stream of the context's previous
+ * launch: a call on another stream first waits on the host for that launch, like every entry point, and capture forbids
+ * that).  No counterpart in the reference.  Same frame, same arguments; the
  * difference is where the launch's per-workgroup counter rows live: in a fixed 4 MiB device array inside the library
  * instead of a block that rt_render_device grows on demand.  Calls no hipMalloc / hipFree.  Limits: workgroups x counters
  * per workgroup <= 2^20 (every frame up to 7680x4320 without collect_events; with collect_events about 26 000 workgroups,

@@ -32,6 +32,8 @@ def load(host_libm: bool = False) -> C.CDLL:
         l.orc_render.restype = C.c_int32
         l.orc_render_with_directions.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_int32]
         l.orc_render_with_directions.restype = C.c_int32
+        l.orc_render_reference_chunks.argtypes = [vp, vp, vp, C.c_uint32, C.c_int32, C.c_uint64, C.c_uint32, vp, vp]
+        l.orc_render_reference_chunks.restype = C.c_int32
         l.orc_ray_directions.argtypes = [vp, vp]; l.orc_ray_directions.restype = None
         l.orc_camera_ray.argtypes = [vp, C.c_uint32, C.c_uint32, vp]; l.orc_camera_ray.restype = None
         l.orc_camera_matrices.argtypes = [vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
@@ -74,6 +76,24 @@ def ray_directions(camera, host_libm=False):
     out = np.zeros((camera.height, camera.width, 3), dtype=np.float32)
     load(host_libm).orc_ray_directions(C.addressof(camera), out.ctypes.data)
     return out
+
+
+def render_reference_chunks(desc, camera, textures=(), frame_index=1, accumulate=False, seed=0x5EED, num_chunks=200, accum=None):
+    """Renderer::render's chunk loop exactly as written (src/renderer.rs:104-143), including the pixel offset of a short last
+    chunk.  Returns dict(rgba, accum); raises OverflowError where the reference panics (fewer pixels than chunks)."""
+    l = load()
+    w, h = camera.width, camera.height
+    if accum is None:
+        accum = np.zeros((h, w, 4), dtype=np.float32)
+    rgba = np.zeros((h, w, 4), dtype=np.uint8)
+    tex, keep = texture_array(list(textures), int(desc.n_textures))
+    st = l.orc_render_reference_chunks(C.addressof(desc), C.addressof(tex), C.addressof(camera), frame_index, int(accumulate), seed, num_chunks,
+                                       accum.ctypes.data, rgba.ctypes.data)
+    if st == -2:
+        raise OverflowError("chunks_mut(0): the reference panics on frames with fewer pixels than chunks (src/renderer.rs:105-107)")
+    if st != 0:
+        raise ValueError("orc_render_reference_chunks rejected the scene")
+    return dict(rgba=rgba, accum=accum)
 
 
 def render(desc, camera, textures=(), frame_index=1, accumulate=False, seed=0x5EED, rows=None, accum=None, n_threads=1,

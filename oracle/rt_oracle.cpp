@@ -878,6 +878,59 @@ int32_t orc_render_with_directions(const rt_scene_desc *sd, const orc_texture *t
     return 0;
 }
 
+// src/renderer.rs:104-143 AS WRITTEN, for whole frames: `img.chunks_mut(img_chunk_size)` yields a short last chunk whenever
+// width * height is not a multiple of num_chunks, and the closure derives that chunk's pixel offset from ITS OWN length
+// (`offset = e.0 * acc_size`, :115-117) instead of the length of the chunks before it.  The short chunk therefore reads the
+// directions and accumulator entries of pixels [n * s, n * s + s) (n = its index, s = its length) while its bytes and, through
+// the sequential copy-back (:138-143), its accumulator entries land at the end of the frame.  orc_render above gives every
+// pixel its own direction (what the GPU backend does); this entry point exists to state the difference exactly.
+// Returns -2 where the reference panics: `chunks_mut(0)` for frames of fewer than num_chunks pixels.
+// The random-number key of a pixel is that of the pixel whose direction is used (the reference's ThreadRng has no such key).
+int32_t orc_render_reference_chunks(const rt_scene_desc *sd, const orc_texture *textures, const rt_camera_desc *camera, uint32_t frame_index,
+                                    int32_t accumulate, uint64_t seed, uint32_t num_chunks, float *accum, uint8_t *rgba) {
+    Scene scene;
+    if (!camera || !accum || !rgba || camera->width == 0 || camera->height == 0 || num_chunks == 0) return -1;
+    if (!load_scene(sd, textures, scene)) return -1;
+    const size_t total = (size_t)camera->width * camera->height;
+    const size_t img_len = total * 4;
+    const size_t img_chunk_size = (img_len / ((size_t)num_chunks * 4)) * 4;   // :105
+    if (img_chunk_size == 0) return -2;                                       // :107 chunks_mut(0) panics
+    const Vec3 position = ld3(camera->position);
+    std::vector<std::vector<Vec4>> col;                                       // :109 one temporary Renderer per chunk
+    size_t e0 = 0;
+    for (size_t start = 0; start < img_len; start += img_chunk_size, e0++) {
+        const size_t buf_len = std::min(img_chunk_size, img_len - start);     // :113
+        const size_t acc_size = buf_len / 4;                                  // :115
+        const size_t offset = e0 * acc_size;                                  // :117
+        std::vector<Vec4> k(acc_size);                                        // :119-122 k.to_vec()
+        for (size_t i = 0; i < acc_size; i++) k[i] = *reinterpret_cast<const Vec4 *>(accum + 4 * (offset + i));
+        uint8_t *bytes = rgba + start;
+        for (size_t pos = 0; pos < acc_size; pos++) {                         // render_chunk, :48-78
+            const size_t src = pos + offset;                                  // :49 camera.ray_directions[pos + chunk.pixel_offset]
+            const Vec3 ray_dir = camera_ray_dir(*camera, (uint32_t)(src % camera->width), (uint32_t)(src / camera->width));
+            const uint32_t key = rng_path_key(seed, (uint32_t)src, frame_index);
+            const Vec4 p = scene_pixel(scene, Ray{position, ray_dir}, key, nullptr);
+            if (accumulate) {
+                k[pos] = k[pos] + p;
+                Vec4 a = k[pos];
+                a = a / (float)frame_index;
+                a = clamp01(a);
+                to_rgba(a, bytes + 4 * pos);
+            } else {
+                k[pos] = clamp01(p);
+                to_rgba(k[pos], bytes + 4 * pos);
+            }
+        }
+        col.push_back(std::move(k));
+    }
+    size_t off = 0;                                                           // :138-143
+    for (const auto &c : col) {
+        for (size_t i = 0; i < c.size(); i++) *reinterpret_cast<Vec4 *>(accum + 4 * (off + i)) = c[i];
+        off += c.size();
+    }
+    return 0;
+}
+
 void orc_camera_ray(const rt_camera_desc *camera, uint32_t x, uint32_t y, float dir[3]) {
     Vec3 d = camera_ray_dir(*camera, x, y);
     dir[0] = d.x; dir[1] = d.y; dir[2] = d.z;

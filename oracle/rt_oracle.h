@@ -42,6 +42,15 @@ int32_t orc_render_with_directions(const rt_scene_desc *scene, const orc_texture
                                    uint32_t row_begin, uint32_t row_end, float *accum, uint8_t *rgba, float *linear,
                                    uint64_t *counters, int32_t n_threads);
 
+/* Renderer::render's chunk loop exactly as written (src/renderer.rs:104-143), whole frames only: with width*height not a
+ * multiple of num_chunks the short last chunk takes the directions and accumulator entries of the pixels at
+ * `chunk index * its own length` (src/renderer.rs:115-117) and writes them to the end of the frame.  orc_render gives every
+ * pixel its own direction instead, as the GPU backend does.  Returns -2 where the reference panics (fewer than num_chunks
+ * pixels: chunks_mut(0)), -1 for an invalid description. */
+int32_t orc_render_reference_chunks(const rt_scene_desc *scene, const orc_texture *textures, const rt_camera_desc *camera,
+                                    uint32_t frame_index, int32_t accumulate, uint64_t seed, uint32_t num_chunks, float *accum,
+                                    uint8_t *rgba);
+
 /* Camera::calculate_ray_directions (src/camera.rs:128-157): out = width*height*3 floats, row-major. */
 void orc_ray_directions(const rt_camera_desc *camera, float *out);
 

@@ -213,3 +213,44 @@ def test_oracle_rejects_out_of_range_indices(pkg, orc):
     sb = SceneBuilder(pkg, [make_object(pkg, pkg.RT_SPHERE, 0, position=(0, 0, 0), radius=1.0)], [make_material(pkg, texture=2)], n_textures=4)
     with pytest.raises(ValueError):
         orc.render(sb.desc, cam)
+
+
+def test_reference_chunk_loop_and_its_short_last_chunk(pkg, orc):
+    """renderer.rs:104-143 as written.  With width*height a multiple of the chunk count the chunk loop is the plain frame.
+    Otherwise `chunks_mut` yields a short last chunk whose pixel offset is computed from its OWN length (:115-117): its s
+    pixels -- the last s of the frame -- show pixels [n*s, n*s + s) of the frame instead (n = its chunk index), bytes and
+    accumulator alike; every other pixel is unaffected.  Frames with fewer pixels than chunks panic (chunks_mut(0))."""
+    s = pkg.Scene("scene3")
+    tex = s.textures()
+    # 40 x 25 = 1000 pixels, 200 chunks of 5: no short chunk
+    cam = s.camera(40, 25)
+    ref = orc.render(s.desc, cam, tex)
+    quirk = orc.render_reference_chunks(s.desc, cam, tex)
+    assert np.array_equal(ref["rgba"], quirk["rgba"]) and np.array_equal(ref["accum"].view(np.uint32), quirk["accum"].view(np.uint32))
+    # (the offset n * s never exceeds the short chunk's true start n * chunk, so the reference's slices stay in bounds)
+    # 10 chunks over 7 x 15 = 105 pixels: chunk = 10 pixels, ten full chunks, then s = 5, n = 10 -> offset 50
+    cam = s.camera(7, 15)
+    ref = orc.render(s.desc, cam, tex)
+    quirk = orc.render_reference_chunks(s.desc, cam, tex, num_chunks=10)
+    a, b = ref["rgba"].reshape(-1, 4), quirk["rgba"].reshape(-1, 4)
+    fa, fb = ref["accum"].reshape(-1, 4).view(np.uint32), quirk["accum"].reshape(-1, 4).view(np.uint32)
+    assert np.array_equal(a[:100], b[:100]) and np.array_equal(fa[:100], fb[:100])          # ten full chunks
+    assert np.array_equal(b[100:105], a[50:55]) and np.array_equal(fb[100:105], fa[50:55])  # the short chunk shows pixels 50..54
+    assert not np.array_equal(a[100:105], b[100:105]), "the test frame must make the difference visible"
+    # accumulation: the short chunk adds this frame's value of pixel 50 + i to the accumulator entry of pixel 50 + i and stores
+    # the sum at 100 + i, so over two frames the tail keeps following pixels 50..54
+    d = pkg.Scene("scene2")
+    cam = d.camera(7, 15)
+    acc_ref = np.zeros((15, 7, 4), dtype=np.float32)
+    acc_q = np.zeros((15, 7, 4), dtype=np.float32)
+    for f in (1, 2):
+        ref = orc.render(d.desc, cam, (), frame_index=f, accumulate=True, seed=5, accum=acc_ref)
+        quirk = orc.render_reference_chunks(d.desc, cam, (), frame_index=f, accumulate=True, seed=5, num_chunks=10, accum=acc_q)
+        fa, fb = acc_ref.reshape(-1, 4).view(np.uint32), acc_q.reshape(-1, 4).view(np.uint32)
+        assert np.array_equal(fa[:100], fb[:100]) and np.array_equal(fb[100:105], fa[50:55])
+        assert np.array_equal(quirk["rgba"].reshape(-1, 4)[100:105], ref["rgba"].reshape(-1, 4)[50:55])
+    # fewer pixels than chunks: the reference panics, the restatement says so; orc_render renders the frame
+    cam = s.camera(13, 15)   # 195 pixels < 200 chunks
+    with pytest.raises(OverflowError):
+        orc.render_reference_chunks(s.desc, cam, tex)
+    assert orc.render(s.desc, cam, tex)["rgba"].shape == (15, 13, 4)

@@ -45,5 +45,18 @@ def test_noalloc_entry_point_equals_render_device_on_two_calls_in_a_row(pkg):
         a = ctx.stats()["rays_total"]
         ctx.render_device(frame_index=1, noalloc=False)
         assert ctx.stats()["rays_total"] == a
+        # no device memory is taken or given back by the entry point: the free memory hipMemGetInfo reports stays the same over
+        # calls that a growing counter block would have made allocate (first frame of a camera, table frame, accumulating frame)
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        for f, acc in ((1, False), (1, False), (2, True), (3, True)):
+            ctx.render_device(frame_index=f, accumulate=acc, noalloc=True, no_timing=True)
+        ctx.stats()
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free_before, "rt_render_device_noalloc changed the amount of free device memory"
+        # flag bits the library does not know are refused, by both entry points
+        for noalloc in (True, False):
+            with pytest.raises(pkg.BackendError, match="unknown bits"):
+                ctx.render_device(frame_index=1, noalloc=noalloc, flags=1 << 9)
     finally:
         ctx.close()
