@@ -326,7 +326,8 @@ def main() -> None:
             if chained:
                 ctx.render_samples_device(ids[0], len(ids), seed=0x5EED, rows=(rows_arg[0], rows_arg[1]) if rows_arg else None,
                                           tile_row_stride=rows_arg[2] if rows_arg else 0, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh)
-                return ctx.stats()["rays_total"], 0
+                st = ctx.stats()
+                return st["rays_total"], st["rays_reused_camera"]
             for idx in ids:
                 render(idx, acc=True if shard == "samples" else accumulate)
                 st = ctx.stats()
@@ -388,7 +389,8 @@ def main() -> None:
             out = {
                 "metric": "Mrays/sec (primary+secondary) and frame ms at 4K",
                 "value": round(value, 2),
-                # the same without the camera rays that the tile classification settled without tracing them
+                # the same without the rays that were settled without tracing them: camera rays of all-sky workgroups (tile
+                # classification) and, in multi-sample launches, camera rays of a pixel's later samples (traced once per pixel)
                 "value_traced_only": round(value_traced, 2),
                 "unit": "Mrays/s",
                 "n_gpus": world,
@@ -403,7 +405,7 @@ def main() -> None:
                 "config": {"workload": f"{workload}: {description}", "width": width, "height": height,
                            "max_ray_bounces": int(scene.desc.max_ray_bounces), "samples_per_step": spp,
                            "rays_per_step_per_rank": int(rays_rank), "traced_rays_per_step": int(round((rays_all - sky_all) / steps)),
-                           "sky_tile_rays_per_step": int(round(sky_all / steps)), "sharding": shard, "clock_prewarm_ms": int(CLOCK_PREWARM_S * 1e3),
+                           "untraced_rays_per_step": int(round(sky_all / steps)), "sharding": shard, "clock_prewarm_ms": int(CLOCK_PREWARM_S * 1e3),
                            "accumulator_store": "n/a (accumulating)" if accumulate or shard == "samples" else ("skipped" if skip_store else "written"),
                            "sky_tiles": sky_tiles,
                            "ranks": world, "backend": backend if use_dist else "none", "exchange_ms_per_step": round(exchange_ms, 4),

@@ -199,6 +199,9 @@ typedef struct rt_stats {
     uint64_t frames_rendered;
     uint64_t rays_sky_tiles; /* part of rays_total: camera rays of workgroups that the tile classification (see
                               * RT_RENDER_NO_SKY_TILES) gave the value of a miss without tracing them; the reference traces them */
+    uint64_t rays_reused_camera; /* part of rays_total: camera rays of rt_render_samples_device that were not traced because
+                              * the same ray -- Camera.ray_directions[pos] does not change between frames -- was traced for
+                              * the pixel's first sample of the call; the reference traces them in every frame */
 } rt_stats;
 
 /* Arguments of one frame.  Mirrors the per-frame state of Renderer (src/renderer.rs:13-18) as

@@ -115,7 +115,8 @@ class rt_camera_desc(C.Structure):
 
 class rt_stats(C.Structure):
     _fields_ = [("rays_total", C.c_uint64), ("counters", C.c_uint64 * RT_CNT_COUNT), ("last_kernel_ms", C.c_double),
-                ("last_copy_ms", C.c_double), ("frames_rendered", C.c_uint64), ("rays_sky_tiles", C.c_uint64)]
+                ("last_copy_ms", C.c_double), ("frames_rendered", C.c_uint64), ("rays_sky_tiles", C.c_uint64),
+                ("rays_reused_camera", C.c_uint64)]
 
 
 class rt_hierarchy_info(C.Structure):
@@ -441,6 +442,7 @@ class Context:
         d["last_copy_ms"] = float(s.last_copy_ms)
         d["frames_rendered"] = int(s.frames_rendered)
         d["rays_sky_tiles"] = int(s.rays_sky_tiles)
+        d["rays_reused_camera"] = int(s.rays_reused_camera)
         return d
 
     def hierarchy_info(self) -> dict:

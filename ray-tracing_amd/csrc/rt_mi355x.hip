@@ -122,6 +122,7 @@ struct rt_ctx {
     const uint32_t *last_counters = nullptr;   // counter table the last render wrote
     std::vector<uint32_t> h_counters;
     uint32_t last_blocks = 0, last_ncnt = 0;
+    uint32_t last_reused_rows = 0;   // > 0: the table has this many more rows behind the first last_blocks: rays counted there but not traced
     bool kernel_timed = false;           // the last launch was bracketed by ev0 / ev1
     bool last_events = false, timed = false;
     hipStream_t last_stream = nullptr;
@@ -583,6 +584,9 @@ int32_t query_wf_groups(rt_ctx *c) {
     RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_wf_chain_kernel, 64, 0));
     if (per_cu <= 0) return fail(c, RT_ERR_DEVICE, "occupancy query of the path tracing kernel failed");
     c->wf_chain_groups = (uint32_t)per_cu * (uint32_t)cus;
+#ifdef RT_CH_GROUPS_PER_CU   // experiment: fewer resident wavefronts than fit
+    c->wf_chain_groups = std::min<uint32_t>(c->wf_chain_groups, (uint32_t)(RT_CH_GROUPS_PER_CU) * (uint32_t)cus);
+#endif
     return RT_OK;
 }
 
@@ -649,6 +653,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         blocks = grid.x * grid.y;
     }
     if (samples > 1u && !regroup) return fail(c, RT_ERR_STATE, "several samples per launch need the re-grouping path tracer");
+    if (samples > kChMaxSamples) return fail(c, RT_ERR_UNSUPPORTED, "more than 2^24 samples in one launch");
     const bool chain = regroup && (samples > 1u || RT_WF_CHAIN_SINGLE != 0);
     WfArgs W = {};
     if (chain) {
@@ -660,12 +665,16 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         grid = dim3((uint32_t)std::min<uint64_t>(c->wf_chain_groups, pools));
         blocks = grid.x;
         const size_t plane = (size_t)c->wf_chain_groups * kChPool;
-        RT_HIP(c, c->wf_pool.ensure(plane * 6u));   // six planes of 16 bytes per pool entry / pixel slot (the sixth half used)
+        // per pixel slot: a, b, c, e, k0, k1, k2 (16 bytes each), h, g (8 bytes each), d1 (4 bytes): 132 bytes, 8.25 planes of 16
+        RT_HIP(c, c->wf_pool.ensure(plane * 9u));
         RT_HIP(c, c->wf_ctrl.ensure((size_t)kWfCtrlRows + tiles_y));
         c->wf_order_key[0] = c->wf_order_key[1] = ~0ull;   // the other kernel's per-row history in this buffer is gone
         RT_HIP(c, hipMemsetAsync(c->wf_ctrl.ptr, 0, sizeof(uint32_t), s));   // the work counter
-        W.a = c->wf_pool.ptr; W.b = W.a + plane; W.c = W.b + plane; W.d = W.c + plane; W.e = W.d + plane;
-        W.g = reinterpret_cast<uint2 *>(W.e + plane);
+        W.a = c->wf_pool.ptr; W.b = W.a + plane; W.c = W.b + plane; W.e = W.c + plane;
+        W.k0 = W.e + plane; W.k1 = W.k0 + plane; W.k2 = W.k1 + plane;
+        W.h = reinterpret_cast<float2 *>(W.k2 + plane);
+        W.g = reinterpret_cast<uint2 *>(W.h + plane);
+        W.d1 = reinterpret_cast<float *>(W.g + plane);
         W.ctrl = c->wf_ctrl.ptr;
     } else if (regroup) {
         { const int32_t r = query_wf_groups(c); if (r != RT_OK) return r; }
@@ -700,7 +709,8 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
             return fail(c, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: the launch needs more than 2^20 counter words (workgroups x counters per workgroup)");
         counters = c->static_counters;
     } else {
-        if (slot == 0u) RT_HIP(c, c->counters.ensure((size_t)blocks * ncnt * slots));   // the first launch of a batch sizes the table
+        // (the first launch of a batch sizes the table; the kernel with sample chains writes a second half, see rt_get_stats)
+        if (slot == 0u) RT_HIP(c, c->counters.ensure((size_t)blocks * ncnt * slots * (chain ? 2u : 1u)));
         counters = c->counters.ptr + (size_t)slot * blocks * ncnt;
     }
 
@@ -852,6 +862,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
     c->kernel_timed = time_kernel;
     c->last_blocks = blocks * (slot + 1u); c->last_ncnt = ncnt; c->last_events = events; c->timed = true; c->last_stream = s;
     c->last_counters = noalloc ? counters : c->counters.ptr;
+    c->last_reused_rows = chain ? blocks : 0u;
 #ifdef RT_DIAG
     if (getenv("RT_DIAG_PRINT")) {
         std::vector<unsigned long long> all((size_t)n_waves * DG_N);
@@ -896,7 +907,15 @@ int32_t rt_render_samples_device(rt_ctx *c, const rt_render_params *p, uint32_t 
     const DevScene &S = c->scene;
     const bool regroup = !S.ray_marching && S.bvh2_nodes && S.diffuse && !c->has_refractive && S.max_ray_bounces >= 1u &&
                          !(p->flags & RT_RENDER_ONE_LANE_PER_PIXEL);
-    if (regroup) return render_impl(c, p, d_rgba8, d_accum, stream, false, sample_count);
+    if (regroup) {
+        rt_render_params q = *p;
+        for (uint32_t done = 0; done < sample_count; done += kChMaxSamples) {   // (one launch unless the batch is longer than 2^24 samples)
+            q.frame_index = p->frame_index + done;
+            const int32_t r = render_impl(c, &q, d_rgba8, d_accum, stream, false, std::min(sample_count - done, kChMaxSamples));
+            if (r != RT_OK) return r;
+        }
+        return RT_OK;
+    }
     // one launch after the other on the caller's stream, each with its own block of counter rows
     rt_render_params q = *p;
     q.no_timing = 1;
@@ -1051,8 +1070,9 @@ int32_t rt_get_stats(rt_ctx *c, rt_stats *out) {
         float ms = 0.0f;
         if (c->kernel_timed && hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) out->last_kernel_ms = ms;
         const size_t n = (size_t)c->last_blocks * c->last_ncnt;
-        c->h_counters.resize(n);
-        RT_HIP(c, hipMemcpy(c->h_counters.data(), c->last_counters, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        c->h_counters.resize(n + c->last_reused_rows);
+        RT_HIP(c, hipMemcpy(c->h_counters.data(), c->last_counters, (n + c->last_reused_rows) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t b = 0; b < c->last_reused_rows; b++) out->rays_reused_camera += c->h_counters[n + b];
         for (uint32_t b = 0; b < c->last_blocks; b++) {
             const uint32_t *row = c->h_counters.data() + (size_t)b * c->last_ncnt;
             out->rays_total += row[0] & 0x7FFFFFFFu;

@@ -75,9 +75,14 @@ struct WfArgs {
     uint32_t *ctrl;   // kWfCtrl* header words, then [kWfCtrlRows + r] = rays traced in tile row r
     uint32_t tiles_x, tiles_y;
     unsigned long long *stats;   // diagnostic builds only
-    // rt_wf_chain_kernel only
-    float4 *e;        // per pixel slot: the pixel's accumulator entry so far (Renderer.accumulated[pos] plus the samples added)
-    uint2 *g;         //                 pixel index, samples of this launch already added
+    // rt_wf_chain_kernel: per pixel slot, planes a (ray origin, RNG key), b (ray direction, contribution x), c (carried light,
+    // contribution y) as above -- only written for bounce rays -- and
+    float *d1;        // contribution z
+    float2 *h;        // closest hit so far: distance, object word (see kChPrimaryBit)
+    float4 *e;        // the pixel's accumulator entry so far (Renderer.accumulated[pos] plus the samples added)
+    uint2 *g;         // pixel index, samples of this launch already added | bounce depth of the current path << 24
+    float4 *k0, *k1, *k2;   // what every sample of the slot's pixel shares, from the pixel's camera ray (see the kernel): origin of the
+                      // first bounce ray + light x, normal at the first hit + light y, contribution + light z
     uint32_t samples; // accumulating frames this launch renders: frame_index = F.frame_index ... F.frame_index + samples - 1
 };
 
@@ -109,8 +114,15 @@ RT_DEV void wf_linear_objects(const DevScene &S, f3 ro, f3 rd, float &closest, i
 
 // trace_ray for the n rays of the pool (stage 0: the tile's camera rays).  In: pd[j].zw = closest hit among the linear
 // objects; out: pd[j].zw = closest hit overall (t bits, object | sub << 30).
+// CHAIN (rt_wf_chain_kernel): the pool is the wavefront's array of pixel slots, used in place.  ph[j] = (closest hit among the
+// linear objects, object word) in, (closest hit overall, object word) out; an object word of kWfHitInvalid marks an empty slot,
+// bit kChPrimaryBit a camera ray, whose origin and direction are not stored: pg[j].x is its pixel.
+constexpr uint32_t kChPrimaryBit = 1u << 29, kChObjMask = 0x0FFFFFFFu;
+RT_DEV uint32_t ch_pack_hit(int best, int best_sub) { return (best < 0 ? kChObjMask : (uint32_t)best) | ((uint32_t)best_sub << 30); }
+template <bool CHAIN = false>
 RT_DEV void wf_trace_pool(const DevScene &S, const DevCamera &C, const DevFrame &F, bool primary, uint32_t n, uint32_t x0, uint32_t y0,
-                          const float4 *pa, const float4 *pb, float4 *pd, uint32_t *s_stack, uint32_t &rays WS_PARAM) {
+                          const float4 *pa, const float4 *pb, float4 *pd, uint32_t *s_stack, uint32_t &rays WS_PARAM,
+                          float2 *ph = nullptr, const uint2 *pg = nullptr) {
     const char *nodes = reinterpret_cast<const char *>(S.bvh2_nodes);   // inner references are byte offsets into this array
     const f3 gorg = ld3(S.bvh2_origin), gscl = ld3(S.bvh2_scale);
     uint32_t *stack = s_stack + threadIdx.x;   // entry e of this lane at stack[e * 64]
@@ -134,7 +146,18 @@ RT_DEV void wf_trace_pool(const DevScene &S, const DevCamera &C, const DevFrame 
                 const uint32_t j = next + rank;
                 if (j < n) {
                     bool valid = true;
-                    if (primary) {
+                    float2 h0 = make_float2(0.0f, 0.0f);
+                    if (CHAIN) {
+                        h0 = ph[j];
+                        const uint32_t hw = __float_as_uint(h0.y);
+                        valid = hw != kWfHitInvalid;
+                        if (valid && (hw & kChPrimaryBit)) {
+                            ro = ld3(C.position); rd = ld3(C.ray_dirs + 3u * (size_t)pg[j].x);
+                        } else if (valid) {
+                            const float4 A = pa[j], B = pb[j];
+                            ro = mk3(A.x, A.y, A.z); rd = mk3(B.x, B.y, B.z);
+                        }
+                    } else if (primary) {
                         uint32_t pos;
                         valid = wf_slot_pixel(C, F, x0, y0, j, pos);
                         if (valid) { ro = ld3(C.position); rd = ld3(C.ray_dirs + 3u * (size_t)pos); }
@@ -143,12 +166,13 @@ RT_DEV void wf_trace_pool(const DevScene &S, const DevCamera &C, const DevFrame 
                         ro = mk3(A.x, A.y, A.z); rd = mk3(B.x, B.y, B.z);
                     }
                     if (valid) {
-                        const float2 h0 = *reinterpret_cast<const float2 *>(&pd[j].z);
+                        if (!CHAIN) h0 = *reinterpret_cast<const float2 *>(&pd[j].z);
                         ridx = (int)j;
                         rays += 1u;
                         closest = h0.x;
                         const uint32_t hb = __float_as_uint(h0.y);
-                        best = hb == kWfHitMiss ? -1 : (int)(hb & 0x0FFFFFFFu); best_sub = hb == kWfHitMiss ? 0 : (int)(hb >> 30);
+                        if (CHAIN) { best = (hb & kChObjMask) == kChObjMask ? -1 : (int)(hb & kChObjMask); best_sub = (int)((hb >> 30) & 1u); }
+                        else { best = hb == kWfHitMiss ? -1 : (int)(hb & 0x0FFFFFFFu); best_sub = hb == kWfHitMiss ? 0 : (int)(hb >> 30); }
                         pend0 = 0; pend1 = 0; sp = 0u; cur = 0;
                         // box test on the quantised planes: t = (origin + q * scale - ro) / rd = q * ka + kb
                         // (the box test only steers the traversal: an approximate reciprocal is as good as the exact quotient).
@@ -242,7 +266,8 @@ RT_DEV void wf_trace_pool(const DevScene &S, const DevCamera &C, const DevFrame 
         // ---- rays with no node left are done
         WS_ADD(WS_FINISH, __ballot(ridx >= 0 && cur < 0 && pend0 == 0));
         if (ridx >= 0 && cur < 0 && pend0 == 0) {
-            *reinterpret_cast<float2 *>(&pd[ridx].z) = make_float2(closest, __uint_as_float(wf_pack_hit(best, best_sub)));
+            if (CHAIN) ph[ridx] = make_float2(closest, __uint_as_float(ch_pack_hit(best, best_sub)));
+            else *reinterpret_cast<float2 *>(&pd[ridx].z) = make_float2(closest, __uint_as_float(wf_pack_hit(best, best_sub)));
             ridx = -1;
         }
     }
@@ -391,26 +416,39 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_diffuse_kernel(const De
 // The same path tracer with per-pixel sample chains: ONE launch renders W.samples accumulating frames
 // (frame_index = F.frame_index ... F.frame_index + samples - 1), the pixels of that many launches of the kernel above.
 //
-// A wavefront's pool entries no longer belong to one tile and one bounce.  Every entry is the current path of a PIXEL SLOT:
-// when a path ends (miss, or depth limit) its value is added to the slot's copy of the pixel's accumulator entry and the entry
-// continues with the SAME pixel's next sample; when the pixel has had all its samples, its accumulator entry and RGBA8 value
-// are written -- once per launch instead of once per sample -- and the slot takes the next pixel of the launch (tiles of 64x8
-// pixels from one counter, pixel by pixel).  A pixel's samples are therefore traced one after the other and added in
-// frame_index order, exactly the order of `self.accumulated[pos] += p` over consecutive frames (src/renderer.rs:59-66), and
-// the random numbers are keyed by (seed, pixel, frame_index, bounce), so every path does the arithmetic it does in the
-// kernels above: accumulator and frame are bit-identical to `samples` launches of them.
-// What it buys: the pool stays full from the first round to the end of the launch whatever the lengths of the paths (no
-// drain per bounce and per tile, every trace pass runs over a full pool of rays at mixed depths), no launch tail and no
-// order kernel per sample, and 36 bytes of frame traffic per pixel and LAUNCH instead of per sample.
+// A wavefront's pool entries no longer belong to one tile and one bounce.  Every entry is a PIXEL SLOT that always holds
+// the current path of one pixel: when the path ends (miss, or depth limit) its value is added to the slot's copy of the
+// pixel's accumulator entry and the slot continues with the SAME pixel's next sample; when the pixel has had all its
+// samples, its accumulator entry and RGBA8 value are written -- once per launch instead of once per sample -- and the slot
+// takes the next pixel of the launch (tiles of 64x8 pixels from one counter, pixel by pixel).  A pixel's samples are
+// therefore traced one after the other and added in frame_index order, exactly the order of `self.accumulated[pos] += p`
+// over consecutive frames (src/renderer.rs:59-66), and the random numbers are keyed by (seed, pixel, frame_index, bounce),
+// so every path does the arithmetic it does in the kernels above: accumulator and frame are bit-identical to `samples`
+// launches of them.
+// What it buys: every slot holds a ray in every round, from the first round to the end of the launch, whatever the lengths
+// of the paths (no drain per bounce and per tile, every trace pass runs over a full pool of rays at mixed depths, nothing is
+// compacted or moved); no launch tail and no order kernel per sample; 36 bytes of frame traffic per pixel and LAUNCH instead
+// of per sample; and a camera ray is not stored at all -- it is its pixel -- so only bounce rays pay the pool's bytes.
+// One camera ray per PIXEL: Camera.ray_directions[pos] is the same in every frame (src/renderer.rs:49; nothing jitters it), so
+// RayTracing::trace_ray of a pixel's camera ray returns the same hit for every sample.  It is traced for the pixel's first
+// sample only; what the later samples need from it -- the hit point offset along the normal (origin of every first bounce ray,
+// src/ray.rs:132), the normal, light_color and contribution after the hit (src/ray_tracing/ray_tracing.rs:101-109) -- is kept
+// in the slot, and a later sample starts with its own random direction from there (src/ray.rs:123-130).  A pixel whose
+// camera ray ends its path by itself (a miss, or a depth limit of 1) has the same value in every sample: the remaining
+// samples are added on the spot.  The launch reports such camera rays apart from the ones it traced (F.counters, second half).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kChTileW = 64u, kChTilePixels = kChTileW * 8u;   // work item: 64x8 pixels = eight 8x8 blocks side by side
-// Pixel slots (= pool entries) per wavefront.  The pool never drains here, so it can be smaller than the other kernel's, and
-// it has to be: every entry is rewritten and re-read each round, and the pools of all resident wavefronts together should
-// stay inside the 256 MB last-level cache (measured at 8K / 64 spp: 512 slots 395 ms, 256 slots 300 ms, 128 slots 310 ms).
+// Pixel slots per wavefront.  No slot is ever idle here, so the pool can be smaller than the other kernel's, and it has to
+// be: every slot is rewritten and re-read each round, and the pools of all resident wavefronts together should stay inside
+// the 256 MB last-level cache.
+// Measured at 8K / 64 spp with 8192 resident wavefronts and 132 bytes per slot: 128 slots 203 ms, 192 slots 194 ms, 256 slots
+// 222 ms, 384 slots 251 ms; 6144 wavefronts of 256 slots (the bytes of 8192 x 192) 212 ms.
 #ifndef RT_CH_POOL
-#define RT_CH_POOL 256
+#define RT_CH_POOL 192
 #endif
 constexpr uint32_t kChPool = RT_CH_POOL;
+static_assert(kChPool % 64u == 0u && kChPool >= 64u, "the shade pass walks the slots in batches of one per lane");
+constexpr uint32_t kChMaxSamples = 1u << 24;   // samples per launch: the slot's sample counter shares a word with the depth
 
 struct WfCursor { uint32_t x0, y0, i, n, exhausted; };   // wave-uniform: the item this wavefront is handing out, pixel by pixel
 
@@ -443,8 +481,12 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_chain_kernel(const DevS
     __shared__ uint32_t s_stack[kWfStack * 64u];
     const uint32_t lane = threadIdx.x;
     const size_t slice = (size_t)blockIdx.x * kChPool;
-    float4 *pa = W.a + slice, *pb = W.b + slice, *pc = W.c + slice, *pd = W.d + slice, *pe = W.e + slice;
+    float4 *pa = W.a + slice, *pb = W.b + slice, *pc = W.c + slice, *pe = W.e + slice;
+    float *pd1 = W.d1 + slice;
+    float2 *ph = W.h + slice;
     uint2 *pg = W.g + slice;
+    float4 *pk0 = W.k0 + slice, *pk1 = W.k1 + slice, *pk2 = W.k2 + slice;
+    uint32_t reused = 0u;   // camera rays of later samples, settled from the pixel's first
     const uint32_t maxd = S.max_ray_bounces, n_samples = W.samples;
     const f3 ambient = ld3(S.ambient);
     const bool jitter = S.enable_accumulation != 0u;
@@ -456,39 +498,44 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_chain_kernel(const DevS
     __syncthreads();
 #endif
     WfCursor cur = {0u, 0u, 0u, 0u, 0u};
-    uint32_t n = 0u;    // paths in the pool
     bool boot = true;   // first pass: every pixel slot is empty and takes its first pixel
     for (;;) {
         if (!boot) {
-            if (n == 0u) break;
-            wf_trace_pool(S, C, F, false, n, 0u, 0u, pa, pb, pd, s_stack, rays WS_PASS);
+            wf_trace_pool<true>(S, C, F, false, kChPool, 0u, 0u, pa, pb, nullptr, s_stack, rays WS_PASS, ph, pg);
             __syncthreads();
         }
         // ---- shade: color_diffuse at every hit / miss of this round (ray_tracing.rs:87-114, :155-157), each path at its own depth
-        const uint32_t n_in = boot ? kChPool : n;
-        uint32_t out = 0u;
-        for (uint32_t base = 0u; base < n_in; base += 64u) {
+        uint32_t live = 0u;
+        for (uint32_t base = 0u; base < kChPool; base += 64u) {
             const uint32_t j = base + lane;
-            const bool alive = j < n_in;
+            float2 H = make_float2(0.0f, __uint_as_float(kWfHitInvalid));
+            uint2 G = make_uint2(0u, 0u);
+            if (!boot) { H = ph[j]; G = pg[j]; }
+            const uint32_t hw = __float_as_uint(H.y);
+            const bool alive = hw != kWfHitInvalid;
             WS_ADD(WS_SHADE, __ballot(alive));
-            uint32_t q = j, depth = 0u, key = 0u;
+            uint32_t pos = G.x, sample = G.y & (kChMaxSamples - 1u), depth = G.y >> 24, key = 0u;
             bool goes_on = false, ended = false;
             f3 no = splat3(0.0f), nd = splat3(0.0f), p = splat3(0.0f), cc = splat3(1.0f), V = splat3(0.0f);
-            if (!boot && alive) {
-                const float4 A = pa[j], B = pb[j], Cv = pc[j], D = pd[j];
-                const f3 ro = mk3(A.x, A.y, A.z), rd = mk3(B.x, B.y, B.z), L = mk3(Cv.x, Cv.y, Cv.z), Cc = mk3(Cv.w, D.x, D.y);
-                key = __float_as_uint(A.w);
-                q = __float_as_uint(B.w) & 0xFFFFu; depth = __float_as_uint(B.w) >> 16;
-                const uint32_t hobj = __float_as_uint(D.w);
-                if (hobj == kWfHitMiss) {
+            if (alive) {
+                f3 ro, rd, L = splat3(0.0f), Cc = splat3(1.0f);
+                if (depth == 0u) {   // camera ray (src/renderer.rs:49-57; RayTracing::albedo seeds light 0, contribution 1)
+                    ro = ld3(C.position); rd = ld3(C.ray_dirs + 3u * (size_t)pos);
+                    key = rt_rng_path_key(F.seed, pos, F.frame_index + sample);
+                } else {
+                    const float4 A = pa[j], B = pb[j], Cv = pc[j];
+                    ro = mk3(A.x, A.y, A.z); rd = mk3(B.x, B.y, B.z); L = mk3(Cv.x, Cv.y, Cv.z); Cc = mk3(B.w, Cv.w, pd1[j]);
+                    key = __float_as_uint(A.w);
+                }
+                if ((hw & kChObjMask) == kChObjMask) {
                     V = L + ambient * Cc;
                     ended = true;
                 } else {
-                    const int obj = (int)(hobj & 0x0FFFFFFFu), sub = (int)(hobj >> 30);
+                    const int obj = (int)(hw & kChObjMask), sub = (int)((hw >> 30) & 1u);
                     HitRec h; Mtl m;
                     h.u = 0.0f; h.v = 0.0f;
                     const DevObject &o = S.objects[obj];
-                    finalize_one<false>(o, S.materials[o.material], ro, rd, D.z, sub, h, m, nocnt);
+                    finalize_one<false>(o, S.materials[o.material], ro, rd, H.x, sub, h, m, nocnt);
                     f3 albedo = m.albedo;
                     if (m.texture >= 0) albedo = tex_from_uv(S.textures[m.texture], h.u, h.v);
                     p = L + m.emission_power * albedo;
@@ -498,6 +545,11 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_chain_kernel(const DevS
                     } else {
                         rt_reflection_ray(rd, h, m.roughness, key, true, jitter, no, nd);
                         cc = Cc * albedo;
+                        if (depth == 0u && n_samples > 1u) {   // the camera ray's hit: shared by every sample of this pixel
+                            pk0[j] = make_float4(no.x, no.y, no.z, p.x);
+                            pk1[j] = make_float4(h.normal.x, h.normal.y, h.normal.z, p.y);
+                            pk2[j] = make_float4(cc.x, cc.y, cc.z, p.z);
+                        }
                         key = rt_rng_child_key(key, 0u);
                         depth += 1u;
                         goes_on = true;
@@ -505,64 +557,82 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_chain_kernel(const DevS
                 }
             }
             // ---- a path that ended: its value joins the pixel's accumulator entry; the pixel goes on with its next sample or is written
-            uint32_t pos = 0u, sample = 0u;
-            bool respawn = false, need_pixel = boot && alive;
+            bool again = false, need_pixel = boot;
             if (ended) {
-                const uint2 G = pg[q];
-                pos = G.x; sample = G.y + 1u;
+                sample += 1u;
                 if (F.accumulate) {
-                    float4 E = pe[q];
+                    float4 E = pe[j];
                     E.x = E.x + V.x; E.y = E.y + V.y; E.z = E.z + V.z; E.w = E.w + 1.0f;   // src/renderer.rs:60
-                    if (sample < n_samples) pe[q] = E;
+                    if (depth == 0u) {   // the camera ray ended the path by itself: so it does in every other frame, with the same value
+                        reused += n_samples - sample;
+                        for (; sample < n_samples; sample++) { E.x = E.x + V.x; E.y = E.y + V.y; E.z = E.z + V.z; E.w = E.w + 1.0f; }
+                    }
+                    if (sample < n_samples) pe[j] = E;
                     else store_summed(F, pos, E, F.frame_index + n_samples - 1u);
                 } else if (sample >= n_samples) {
                     store_pixel(F, pos, V);
                 }
-                if (sample < n_samples) { pg[q] = make_uint2(pos, sample); respawn = true; }
+                if (sample < n_samples) again = true;
                 else need_pixel = true;
             }
+            if (again) {   // the pixel's next frame: its camera ray's hit is known, the path starts with its own first bounce ray
+                const float4 K0 = pk0[j], K1 = pk1[j], K2 = pk2[j];
+                HitRec h;
+                h.normal = mk3(K1.x, K1.y, K1.z);
+                key = rt_rng_path_key(F.seed, pos, F.frame_index + sample);
+                const f3 rnd = mk3(rt_rng_uniform(key, 0u, -1.0f, 1.0f), rt_rng_uniform(key, 1u, -1.0f, 1.0f), rt_rng_uniform(key, 2u, -1.0f, 1.0f));
+                nd = normalize(h.normal + rnd);   // Ray::reflection_ray, diffuse branch (src/ray.rs:123-130)
+                no = mk3(K0.x, K0.y, K0.z);
+                p = mk3(K0.w, K1.w, K2.w);
+                cc = mk3(K2.x, K2.y, K2.z);
+                key = rt_rng_child_key(key, 0u);
+                depth = 1u;
+                goes_on = true;
+                reused += 1u;
+            }
+            bool respawn = false;
             // ---- empty pixel slots take the launch's next pixels
             if (__ballot(need_pixel) != 0ull) {
                 uint32_t npos = 0u;
                 const bool got = wf_claim_pixel(C, F, W, cur, need_pixel, npos);
                 if (need_pixel && got) {
                     pos = npos; sample = 0u;
-                    pe[q] = load_accum(F, pos);
-                    pg[q] = make_uint2(pos, 0u);
+                    pe[j] = load_accum(F, pos);
                     respawn = true;
                 }
             }
-            if (respawn) {   // camera ray of this pixel's next frame (src/renderer.rs:49-57; RayTracing::albedo seeds light 0, contribution 1)
+            if (respawn) {   // the camera ray of this pixel's next frame: only its pixel and its first-hit candidate are stored
                 no = ld3(C.position); nd = ld3(C.ray_dirs + 3u * (size_t)pos);
-                p = splat3(0.0f); cc = splat3(1.0f);
-                key = rt_rng_path_key(F.seed, pos, F.frame_index + sample);
                 depth = 0u;
-                goes_on = true;
             }
             // the next ray against the linear objects (wave-uniform loop: kept outside the divergent code above)
             float nclosest = RT_F32_MAX;
             int nbest = -1, nbest_sub = 0;
-            if (S.n_bvh2_linear != 0u && __ballot(goes_on) != 0ull) {
-                if (goes_on) wf_linear_objects(S, no, nd, nclosest, nbest, nbest_sub);
+            if (S.n_bvh2_linear != 0u && __ballot(goes_on || respawn) != 0ull) {
+                if (goes_on || respawn) wf_linear_objects(S, no, nd, nclosest, nbest, nbest_sub);
             }
-            // every lane has read its entry: the compacted writes below never reach an entry that is still unread
-            const uint64_t on = __ballot(goes_on);
             if (goes_on) {
-                const uint32_t k = out + __builtin_amdgcn_mbcnt_hi((uint32_t)(on >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)on, 0u));
-                pa[k] = make_float4(no.x, no.y, no.z, __uint_as_float(key));
-                pb[k] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(q | (depth << 16)));
-                pc[k] = make_float4(p.x, p.y, p.z, cc.x);
-                pd[k] = make_float4(cc.y, cc.z, nclosest, __uint_as_float(wf_pack_hit(nbest, nbest_sub)));
+                pa[j] = make_float4(no.x, no.y, no.z, __uint_as_float(key));
+                pb[j] = make_float4(nd.x, nd.y, nd.z, cc.x);
+                pc[j] = make_float4(p.x, p.y, p.z, cc.y);
+                pd1[j] = cc.z;
             }
-            out += (uint32_t)__popcll(on);
+            if (goes_on || respawn) {
+                ph[j] = make_float2(nclosest, __uint_as_float(ch_pack_hit(nbest, nbest_sub) | (respawn ? kChPrimaryBit : 0u)));
+                pg[j] = make_uint2(pos, sample | (depth << 24));
+            } else if (alive || boot) {
+                ph[j] = make_float2(0.0f, __uint_as_float(kWfHitInvalid));   // no pixel left for this slot
+            }
+            live += (uint32_t)__popcll(__ballot(goes_on || respawn));
         }
-        __syncthreads();   // pool writes of all lanes before the next round reads them
-        n = out;
+        __syncthreads();   // slot writes of all lanes before the next round reads them
         boot = false;
+        if (live == 0u) break;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) rays += __shfl_xor(rays, off, 64);
-    if (lane == 0u) F.counters[blockIdx.x] = rays;
+    for (int off = 32; off > 0; off >>= 1) { rays += __shfl_xor(rays, off, 64); reused += __shfl_xor(reused, off, 64); }
+    // first half of the table: trace_ray invocations of the reference (traced here or not); second half: the ones not traced
+    if (lane == 0u) { F.counters[blockIdx.x] = rays + reused; F.counters[gridDim.x + blockIdx.x] = reused; }
 #ifdef RT_WF_STATS
     __syncthreads();
     if (lane < 2u * WS_N && W.stats) atomicAdd(&W.stats[lane], (unsigned long long)s_stat[lane]);

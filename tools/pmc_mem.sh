@@ -18,7 +18,7 @@ agg=collections.defaultdict(list)
 for f in glob.glob("gpurun_out/pmcmem_${WL}_${tag}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"]
-        if ("rt_trace_kernel<false" in k or "rt_march_kernel<false" in k or "rt_wf_diffuse" in k or "rt_refill_diffuse" in k):
+        if ("rt_trace_kernel<false" in k or "rt_march_kernel<false" in k or "rt_wf_diffuse" in k or "rt_wf_chain" in k or "rt_refill_diffuse" in k):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for c,v in sorted(agg.items()):
     print(f"  {c:40s} {sum(v)/len(v):18.0f}")
