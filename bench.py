@@ -99,6 +99,8 @@ def main() -> None:
                     help="default workload only: without the ride-along measurements (8K / 10 000-sphere / 64-spp frame; moving camera; animated scene)")
     ap.add_argument("--keep-accum-store", action="store_true",
                     help="non-accumulating workloads: also write the frame's linear value to the accumulator (default: RT_RENDER_SKIP_ACCUM_STORE)")
+    ap.add_argument("--march-all-entries", action="store_true",
+                    help="ray-marching scenes: every march step evaluates every entry of Scene.sdfs (RT_RENDER_MARCH_ALL_ENTRIES)")
     ap.add_argument("--no-sky-tiles", action="store_true",
                     help="small scenes: render without the per-tile classification that lets workgroups of sky end without tracing (RT_RENDER_NO_SKY_TILES)")
     args = ap.parse_args()
@@ -206,7 +208,8 @@ def main() -> None:
             # the timed region is bracketed by this script's own events, so the library's per-launch timing events are off
             skip = skip_store if skip is None else skip
             ctx.render_device(frame_index=sample_index if acc else 1, accumulate=acc, seed=0x5EED,
-                              flags=(pkg.RT_RENDER_SKIP_ACCUM_STORE if (skip and not acc) else 0) | (pkg.RT_RENDER_NO_SKY_TILES if args.no_sky_tiles else 0),
+                              flags=(pkg.RT_RENDER_SKIP_ACCUM_STORE if (skip and not acc) else 0) | (pkg.RT_RENDER_NO_SKY_TILES if args.no_sky_tiles else 0) |
+                                    (pkg.RT_RENDER_MARCH_ALL_ENTRIES if args.march_all_entries else 0),
                               rows=(rows[0], rows[1]) if rows else None, tile_row_stride=rows[2] if rows else 0,
                               d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh, no_timing=not events, collect_events=events)
 

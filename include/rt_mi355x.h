@@ -222,7 +222,7 @@ typedef struct rt_render_params {
     uint32_t flags;          /* rt_render_flag bits, 0 for the default behaviour                       */
 } rt_render_params;
 
-/* rt_render_params.flags.  Neither flag changes a pixel. */
+/* rt_render_params.flags.  No flag changes a pixel. */
 typedef enum rt_render_flag {
     /* Diffuse scenes (Scene.diffuse set, no refractive material) are normally traced by kernels that do not keep one
      * pixel per lane for a whole path: large scenes (hierarchy in use) by the kernel that re-groups rays between bounces,
@@ -240,7 +240,12 @@ typedef enum rt_render_flag {
      * being traced.  The classification is recomputed whenever the scene, the camera or the rows of the launch change.  This flag
      * renders without it (A/B runs and tests that compare the two). */
     RT_RENDER_NO_SKY_TILES = 8,
-    RT_RENDER_ALL_FLAGS = 15   /* any other bit in params.flags is refused with RT_ERR_INVALID_ARGUMENT */
+    /* Ray-marching scenes: a march step (src/ray_marching/ray_marching.rs:186-199) normally evaluates only the entries of
+     * Scene.sdfs that can hold the smallest distance -- an entry whose distance function cannot have fallen below the running
+     * minimum since its last evaluation is left out.  This flag evaluates every entry in every step, as RayMarching::sdfs does
+     * (A/B runs and tests that compare the two). */
+    RT_RENDER_MARCH_ALL_ENTRIES = 16,
+    RT_RENDER_ALL_FLAGS = 31   /* any other bit in params.flags is refused with RT_ERR_INVALID_ARGUMENT */
 } rt_render_flag;
 
 /* Creates a context bound to HIP device `device_id` (one context per GPU; one process per GPU

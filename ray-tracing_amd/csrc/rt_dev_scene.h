@@ -119,6 +119,12 @@ struct DevFrame {
     uint32_t row_begin, row_end;
     uint32_t tile_row_step;  // rows between the starts of consecutive tile rows of this launch: 8, or 8 N for an interleaved share
     uint32_t leaf_slots;  // march kernel: object-space rays cached in LDS (0: none)
+    // march kernel, entries of Scene.sdfs that a march step may leave out (see rm_sdfs_march); march_skip = 0: none are.
+    // march_lip[k]: an upper bound of how fast entry k's distance function can fall along a ray, per unit of the march
+    // parameter; march_slot[k]: index of the entry's first cached object-space ray.
+    uint32_t march_skip;
+    float march_lip[8];
+    uint32_t march_slot[8];
     int32_t accumulate;
     int32_t skip_accum_store;  // accumulate == 0 only: do not write the frame's linear value to the accumulator
     uint64_t seed;

@@ -1102,6 +1102,39 @@ RT_DEV uint32_t rm_sdfs(const DevScene &S, f3 ro, f3 rd, float t, SdfOut &best, 
     return obj_idx;
 }
 
+// RayMarching::sdfs inside march_ray's loop (src/ray_marching/ray_marching.rs:186-199), where only the smallest distance
+// matters.  An entry of Scene.sdfs whose distance function cannot have fallen below the running minimum since it was last
+// evaluated is left out: along a ray, a distance function falls by at most `lip` per unit of the march parameter (the leaf
+// functions are exact or conservative distances in their object spaces, so `lip` is the largest stretch of the object's
+// inv_transform times |direction|; a smooth union or a subtraction falls no faster than its faster child), hence
+//     value(t) >= value(t_k) - lip * (t - t_k)      for t >= t_k, the parameter of the entry's last evaluation
+// (t only grows while a ray marches: a step that does not end the loop is >= 0.001).  With a margin for the rounding of the
+// evaluations (2e-3, a thousand times their error at these magnitudes; lip comes inflated by 1e-3 from the host), an entry
+// with bound > minimum-so-far cannot change `d.dist < best.dist` (:47-52), so the minimum -- the only thing march_ray reads
+// -- is the reference's, bit for bit.  The decision is taken per wavefront (an evaluation costs the same for one lane as
+// for sixty-four), every lane that marches takes part in an evaluation and renews its bound.  lb: this lane's column,
+// entry k at lb[k * kMarchThreads], holding value(t_k) + lip * t_k - margin.
+template <bool CACHED>
+RT_DEV float rm_sdfs_march(const DevScene &S, const DevFrame &F, f3 ro, f3 rd, float t, RayCache &rc, float *lb) {
+    Cnt<false> nocnt;
+    float best = RT_F32_MAX;
+    const uint32_t n = S.n_sdfs;
+    for (uint32_t k = 0; k < n; k++) {
+        const float lip = F.march_lip[k];
+        const float bound = lb[k * kMarchThreads] - lip * t;
+        if (__ballot(!(bound > best)) == 0ull) continue;   // (a NaN bound never skips)
+        const DevObject &o = S.objects[S.sdfs[k]];
+        const int kind = o.kind;
+        if (kind == RT_TRIANGLE || kind == RT_CONE) continue;  // the `_ => {}` arm (:95)
+        rc.slot = F.march_slot[k];
+        SdfOut d;
+        Sdf<false, false, 2, CACHED>::eval(S, o, ro, rd, t, d, nocnt, rc);
+        lb[k * kMarchThreads] = (d.dist + lip * t) - 2e-3f;
+        if (d.dist < best) best = d.dist;
+    }
+    return best;
+}
+
 // Fills the RayCache for the world ray (ro, rd): visits the leaves in the order Sdf::eval does and stores their
 // object-space rays.  ro is the same for every lane of the workgroup; thread 0 stores the transformed origins.
 template <int LEVEL>
@@ -1136,7 +1169,9 @@ RT_DEV void rm_fill_cache(const DevScene &S, f3 ro, f3 rd, RayCache &rc) {
 
 // CACHE: the march loop reads the leaves' object-space rays from LDS (dynamic LDS: n_leaf_slots * 3 * (kMarchThreads + 1)
 // floats); chosen by the host when the scene's leaf count fits.  Launched with kMarchThreads threads per workgroup.
-template <bool EVENTS, bool CACHE>
+// SKIP (timed variant only, at most 8 entries in Scene.sdfs): march steps evaluate only the entries that can hold the
+// minimum (rm_sdfs_march; dynamic LDS: n_sdfs * kMarchThreads more floats behind the ray cache).
+template <bool EVENTS, bool CACHE, bool SKIP = false>
 __global__ void __launch_bounds__(256, 8) rt_march_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
     extern __shared__ float s_ray[];
     __shared__ uint32_t s_cnt[(EVENTS ? RT_CNT_COUNT : 0) + 1];
@@ -1171,11 +1206,14 @@ __global__ void __launch_bounds__(256, 8) rt_march_kernel(const DevScene S, cons
         cnt.ray(RT_CNT_RAYS_MARCH);
         float t = 0.0f, t_eval = 0.0f;
         bool hit = false;
+        float *lb = s_ray + F.leaf_slots * (3u * kMarchThreads + 3u) + threadIdx.x;   // behind the ray cache
+        if (SKIP) for (uint32_t k = 0; k < S.n_sdfs; k++) lb[k * kMarchThreads] = -RT_F32_MAX;   // nothing evaluated yet
         for (int i = 0; i < 255; i++) {
             if (t > 40.0f) break;
             cnt.add(RT_CNT_MARCH_STEP);
             SdfOut d;
-            rm_sdfs<EVENTS, false, CACHE>(S, ro, rd, t, d, cnt, rc);
+            if (SKIP) d.dist = rm_sdfs_march<CACHE>(S, F, ro, rd, t, rc, lb);
+            else rm_sdfs<EVENTS, false, CACHE>(S, ro, rd, t, d, cnt, rc);
             t_eval = t;
             t = t + d.dist;
             if (d.dist < 0.001f) { hit = true; break; }

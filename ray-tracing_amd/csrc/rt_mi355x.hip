@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -90,6 +91,7 @@ struct rt_ctx {
     DevTexture h_textures[kMaxTextures] = {};
     std::vector<int32_t> mat_texture;  // texture index of every material, for the render-time check
     std::vector<rt_object> h_objects;  // host copy of the scene's objects (rt_update_objects, hierarchy rebuilds)
+    std::vector<uint32_t> h_sdfs;      // host copy of Scene.sdfs
 
     DevScene scene = {};
     DevCamera camera = {};
@@ -241,6 +243,49 @@ hipError_t fill_ray_directions(rt_ctx *c, hipStream_t s) {
     const hipError_t e = hipGetLastError();
     if (e == hipSuccess) c->dirs_valid = true;
     return e;
+}
+
+// Largest factor by which the 3x3 part of a column-major 4x4 matrix stretches a vector (its spectral norm), rounded up: the
+// square root of the largest eigenvalue of A^T A, by Jacobi rotations in binary64.
+double stretch3(const float *m) {
+    double a[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            a[i][j] = 0.0;
+            for (int r = 0; r < 3; r++) a[i][j] += (double)m[4 * i + r] * (double)m[4 * j + r];   // columns i and j
+        }
+    for (int sweep = 0; sweep < 32; sweep++)
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (std::fabs(a[p][q]) < 1e-300) continue;
+                const double theta = 0.5 * std::atan2(2.0 * a[p][q], a[q][q] - a[p][p]), cs = std::cos(theta), sn = std::sin(theta);
+                double b[3][3];
+                std::memcpy(b, a, sizeof(b));
+                for (int k = 0; k < 3; k++) { b[k][p] = cs * a[k][p] - sn * a[k][q]; b[k][q] = sn * a[k][p] + cs * a[k][q]; }
+                std::memcpy(a, b, sizeof(a));
+                for (int k = 0; k < 3; k++) { b[p][k] = cs * a[p][k] - sn * a[q][k]; b[q][k] = sn * a[p][k] + cs * a[q][k]; }
+                std::memcpy(a, b, sizeof(a));
+            }
+    const double ev = std::max(a[0][0], std::max(a[1][1], a[2][2]));
+    // the rotations leave the trace alone and only shrink the off-diagonal part: whatever is left of it is added as a bound
+    const double off = std::fabs(a[0][1]) + std::fabs(a[0][2]) + std::fabs(a[1][2]);
+    return std::sqrt(std::max(ev + 2.0 * off, 0.0));
+}
+
+// How fast the distance function of object i (Object3D::sdf, src/objects.rs:33-44) can fall along a ray, per unit length:
+// the leaf functions are distances (or, for the sphere's `length(p) - radius`, 1-Lipschitz) in the object's space, so the
+// bound is the stretch of inv_transform; a plane's is |normal|; a smooth union or a subtraction falls no faster than the
+// faster of its children.  Infinity where no bound is known (such an entry is evaluated in every step).
+double march_fall_rate(const std::vector<rt_object> &objs, uint32_t i, int level) {
+    const rt_object &o = objs[i];
+    switch (o.kind) {
+        case RT_SPHERE: case RT_CUBOID: case RT_CYLINDER: return stretch3(o.inv_transform);
+        case RT_PLANE: return std::sqrt((double)o.normal[0] * o.normal[0] + (double)o.normal[1] * o.normal[1] + (double)o.normal[2] * o.normal[2]);
+        case RT_UNION: case RT_SUBSTRACTION:
+            if (level <= 0 || o.first < 0 || o.second < 0) return HUGE_VAL;
+            return std::max(march_fall_rate(objs, (uint32_t)o.first, level - 1), march_fall_rate(objs, (uint32_t)o.second, level - 1));
+        default: return 0.0;   // cone, triangle: never evaluated (src/ray_marching/ray_marching.rs:95)
+    }
 }
 
 // A render may have been launched on a caller's stream; anything that touches the same buffers from another
@@ -434,6 +479,7 @@ int32_t rt_set_scene(rt_ctx *c, const rt_scene_desc *d) {
     S.diffuse = d->diffuse; S.enable_accumulation = d->enable_accumulation;
 
     c->h_objects.assign(d->objects, d->objects + d->n_objects);
+    c->h_sdfs.assign(d->sdfs, d->sdfs + d->n_sdfs);
     { int32_t r = upload_hierarchy(c); if (r != RT_OK) return r; }
     c->leaf_slots = 0;
     if (d->ray_marching) {
@@ -726,6 +772,8 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
 
     DevFrame F;
     F.frame_index = p->frame_index; F.row_begin = rb; F.row_end = re; F.tile_row_step = 8u * stride; F.leaf_slots = 0; F.accumulate = p->accumulate; F.seed = p->seed;
+    F.march_skip = 0u;
+    for (int k = 0; k < 8; k++) { F.march_lip[k] = 0.0f; F.march_slot[k] = 0u; }
     F.skip_accum_store = (!p->accumulate && (p->flags & RT_RENDER_SKIP_ACCUM_STORE)) ? 1 : 0;
     F.rgba = d_rgba8 ? (uint32_t *)d_rgba8 : c->rgba.ptr;
     F.accum = d_accum ? (float *)d_accum : c->accum.ptr;
@@ -823,8 +871,34 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         // up to 16 leaves (12.5 KiB of LDS per 64-thread workgroup) keep their object-space rays in LDS during the march loop
         const bool cache = c->leaf_slots >= 1u && c->leaf_slots <= (uint32_t)RT_MARCH_CACHE_MAX_SLOTS;
         F.leaf_slots = cache ? c->leaf_slots : 0u;
-        const size_t lds = cache ? (size_t)c->leaf_slots * 3u * (threads + 1u) * sizeof(float) : 0u;
-        if (cache) {
+        size_t lds = cache ? (size_t)c->leaf_slots * 3u * (threads + 1u) * sizeof(float) : 0u;
+        // march steps that leave out the entries of Scene.sdfs which cannot hold the minimum (rm_sdfs_march): 2 to 8 entries
+        // with known bounds, timed variant only (the counting variant evaluates what the reference evaluates)
+        bool skip = !events && S.n_sdfs >= 2u && S.n_sdfs <= 8u && !(p->flags & RT_RENDER_MARCH_ALL_ENTRIES);
+        if (skip) {
+            uint32_t slot = 0u;
+            for (uint32_t k = 0; k < S.n_sdfs && skip; k++) {
+                const uint32_t idx = c->h_sdfs[k];
+                const double rate = march_fall_rate(c->h_objects, idx, 2) * 1.001;
+                if (!(rate < 1e30)) skip = false;
+                F.march_lip[k] = (float)rate;
+                if ((double)F.march_lip[k] < rate) F.march_lip[k] = std::nextafter(F.march_lip[k], HUGE_VALF);
+                F.march_slot[k] = slot;
+                const int kind = c->h_objects[idx].kind;
+                if (cache && kind != RT_TRIANGLE && kind != RT_CONE) {
+                    rt_scene_desc d1;
+                    std::memset(&d1, 0, sizeof(d1));
+                    d1.objects = c->h_objects.data(); d1.n_objects = (uint32_t)c->h_objects.size();
+                    slot += march_leaf_slots(&d1, idx, 2);
+                }
+            }
+        }
+        F.march_skip = skip ? 1u : 0u;
+        if (skip) {
+            lds += (size_t)S.n_sdfs * threads * sizeof(float);
+            if (cache) launch(rt_march_kernel<false, true, true>, grid, threads, lds, s, S, cam, F);
+            else launch(rt_march_kernel<false, false, true>, grid, threads, lds, s, S, cam, F);
+        } else if (cache) {
             if (events) launch(rt_march_kernel<true, true>, grid, threads, lds, s, S, cam, F);
             else launch(rt_march_kernel<false, true>, grid, threads, lds, s, S, cam, F);
         } else {

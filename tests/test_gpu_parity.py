@@ -1120,6 +1120,23 @@ def test_random_diffuse_scenes_through_the_regrouping_path_tracer(pkg, orc, ctx,
     for flags, (rgba, accum, rays) in bufs.items():
         assert_parity(rgba, ref["rgba"], accum, acc, what=f"random diffuse scene {seed}, flags {flags}")
         assert rays == ref_rays
+    # the same three frames as ONE launch (rt_render_samples_device: every pixel's samples one after the other, its camera ray
+    # traced once), then a second launch that continues from that accumulator with jittered-free frames 4 and 5: equal to the
+    # oracle's five frames, bytes, accumulator and ray count (max_ray_bounces 1 ends every path at its camera ray)
+    rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    ctx.render_samples_device(1, 3, seed=31 + seed, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr())
+    st = ctx.stats()
+    assert st["rays_total"] == ref_rays and 0 < st["rays_reused_camera"] <= 2 * w * h
+    assert_parity(rgba.cpu().numpy(), ref["rgba"], accum.cpu().numpy(), acc, what=f"random diffuse scene {seed}, three samples in one launch")
+    ctx.render_samples_device(4, 2, seed=31 + seed, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr())
+    more = ctx.stats()["rays_total"]
+    ref_more = 0
+    for f in (4, 5):
+        ref = orc.render(sb.desc, cam, tex, frame_index=f, accumulate=True, seed=31 + seed, accum=acc, n_threads=8, want_counters=True)
+        ref_more += sum(ref["counters"][:5])
+    assert more == ref_more
+    assert_parity(rgba.cpu().numpy(), ref["rgba"], accum.cpu().numpy(), acc, what=f"random diffuse scene {seed}, samples 4-5 continued")
 
 
 @pytest.mark.parametrize("seed", list(range(6)))
@@ -1155,6 +1172,37 @@ def test_random_scenes_in_the_random_number_modes(pkg, orc, ctx, seed):
     other = ctx.render(frame_index=1, accumulate=True, reset_accum=True, seed=1)
     first = orc.render(sb.desc, cam, (), frame_index=1, accumulate=True, seed=4242 + seed)
     assert not np.array_equal(other, first["rgba"]), "the seed has no effect"
+
+
+@pytest.mark.parametrize("name,size", [("scene4", (800, 600)), ("scene4", (333, 77)), ("scene4", (3840, 2160))])
+def test_march_steps_that_leave_entries_out_change_no_pixel(pkg, orc, ctx, name, size):
+    """A march step evaluates only the entries of Scene.sdfs that can hold the smallest distance (bounds from each entry's last
+    evaluation); RT_RENDER_MARCH_ALL_ENTRIES evaluates all of them, as RayMarching::sdfs does.  Same frame, bit for bit, for the
+    scene's own camera, for cameras inside and grazing the objects, and after the animated objects have moved."""
+    s = pkg.Scene(name)
+    w, h = size
+    ctx.load(s, w, h)
+    poses = [None, ((0.0, 0.4, 1.0), (0.3, -0.1, -1.0)), ((-1.0, 0.9, 0.25), (0.0, -0.05, -1.0)), ((2.0, 6.0, 3.0), (-0.3, -1.0, -0.8)), ((0.0, 1.0, -2.0), (0.0, 0.2, 1.0))]
+    objs = [pkg.rt_object.from_buffer_copy(s.desc.objects[i]) for i in range(s.desc.n_objects)]
+    for k, pose in enumerate(poses if w * h <= 800 * 600 else poses[:2]):
+        cam = s.camera(w, h) if pose is None else pkg.make_camera(pose[0], pose[1], w, h)
+        ctx.set_camera(cam)
+        if k == 3:   # what the scene's update function does: the sphere and the cylinder move (src/bin/scene4.rs:14-26)
+            for i in (2, 3):
+                objs[i].position[0] += 0.7; objs[i].position[1] += 0.35; objs[i].rotation_axis[2] += 30.0
+                pkg.host().rth_object_update(C.byref(objs[i]))
+            ctx.update_objects(2, objs[2:4])
+            for i in (2, 3):
+                s.desc.objects[i] = objs[i]
+        got = []
+        for flags in (0, pkg.RT_RENDER_MARCH_ALL_ENTRIES):
+            ctx.render_device(frame_index=1, flags=flags)
+            got.append((ctx.read_accum().copy(), ctx.stats()["rays_total"]))
+        assert got[0][1] == got[1][1]
+        assert np.array_equal(got[0][0].view(np.uint32), got[1][0].view(np.uint32)), f"pose {k}: leaving entries out changed the frame"
+        if w * h <= 800 * 600:
+            ref = orc.render(s.desc, cam, s.textures(), n_threads=16)
+            assert np.array_equal(got[0][0].view(np.uint32), ref["accum"].view(np.uint32)), f"pose {k} differs from the oracle"
 
 
 @pytest.mark.parametrize("seed", list(range(8)))

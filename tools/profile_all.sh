@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box: tools/profile.sh for every bench workload, then one plain bench line per workload.
 # usage: tools/profile_all.sh <tag> [workloads...]
-TAG=${1:-r02}; shift
-WLS=${@:-scene3_4k scene1_4k tex4_4k scene4_4k scene2_4k spheres10k_4k spheres10k_8k scene3_800x600}
+TAG=${1:-r03}; shift
+WLS=${@:-scene3_4k scene1_4k tex4_4k scene4_4k scene2_4k spheres10k_4k spheres10k_8k scene3_800x600 scene3_4k_moving scene1_4k_animated}
 mkdir -p gpurun_out/bench_$TAG
 for wl in $WLS; do
   bash tools/profile.sh "$TAG" "$wl" > gpurun_out/prof_${TAG}_${wl}.log 2>&1 || { echo "profile of $wl failed"; tail -3 gpurun_out/prof_${TAG}_${wl}.log; exit 1; }

@@ -9,8 +9,8 @@
 bench.py reports `roofline.traffic` only when the stored sha256 equals the running library's.
 
 Bytes per render call: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte read requests at
-64 bytes, so the read side is doubled.  A render call may be several dispatches (the queue-based path tracer launches one
-kernel per bounce): the sums over all timed render kernels are divided by the number of render calls, which is the
+64 bytes, so the read side is doubled.  A render call may be several dispatches (the re-grouping path tracer launches an
+order kernel in front of its render kernel): the sums over all timed render kernels are divided by the number of render calls, which is the
 dispatch count of the kernel that runs once per call.
 """
 import csv
@@ -23,7 +23,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RENDER_KERNELS = ("rt_trace_kernel<false", "rt_march_kernel<false", "rt_wf_", "rt_refill_diffuse_kernel")   # timed variants; the counting variants are <true, ...>
-ONCE_PER_CALL = ("rt_trace_kernel<false", "rt_march_kernel<false", "rt_wf_diffuse_kernel", "rt_refill_diffuse_kernel")
+ONCE_PER_CALL = ("rt_trace_kernel<false", "rt_march_kernel<false", "rt_wf_diffuse_kernel", "rt_wf_chain_kernel", "rt_refill_diffuse_kernel")
 
 
 def sha256(path):
