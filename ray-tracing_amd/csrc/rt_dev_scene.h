@@ -125,6 +125,11 @@ struct DevFrame {
     uint32_t march_skip;
     float march_lip[8];
     uint32_t march_slot[8];
+    // entries that are a Union or a Substraction of two leaves (bit k of march_pair): the second child has a bound of its own
+    // (march_lip2, cached ray march_slot2) and is left out while it cannot influence the pair's value
+    uint32_t march_pair;
+    float march_lip2[8];
+    uint32_t march_slot2[8];
     int32_t accumulate;
     int32_t skip_accum_store;  // accumulate == 0 only: do not write the frame's linear value to the accumulator
     uint64_t seed;

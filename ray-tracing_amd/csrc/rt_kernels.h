@@ -1113,23 +1113,47 @@ RT_DEV uint32_t rm_sdfs(const DevScene &S, f3 ro, f3 rd, float t, SdfOut &best, 
 // with bound > minimum-so-far cannot change `d.dist < best.dist` (:47-52), so the minimum -- the only thing march_ray reads
 // -- is the reference's, bit for bit.  The decision is taken per wavefront (an evaluation costs the same for one lane as
 // for sixty-four), every lane that marches takes part in an evaluation and renews its bound.  lb: this lane's column,
-// entry k at lb[k * kMarchThreads], holding value(t_k) + lip * t_k - margin.
-template <bool CACHED>
-RT_DEV float rm_sdfs_march(const DevScene &S, const DevFrame &F, f3 ro, f3 rd, float t, RayCache &rc, float *lb) {
+// entry k at lb[k * kMarchThreads], holding value(t_k) + lip * t_k - margin (second children of pairs: at n_sdfs + k).
+// UPDATE: a march step at parameter t of the camera ray (bounds are taken at `at` = t and renewed).  Otherwise a tap of
+// RayMarching::normal or ::occlusion (:109-158) at a point within `away` of the camera ray's point at parameter `at` (the last
+// march step's): the bounds are taken there, lowered by lip * away, and left as they are.
+template <bool CACHED, bool UPDATE>
+RT_DEV float rm_sdfs_march(const DevScene &S, const DevFrame &F, f3 ro, f3 rd, float t, RayCache &rc, float *lb, float at, float away) {
     Cnt<false> nocnt;
     float best = RT_F32_MAX;
     const uint32_t n = S.n_sdfs;
     for (uint32_t k = 0; k < n; k++) {
         const float lip = F.march_lip[k];
-        const float bound = lb[k * kMarchThreads] - lip * t;
+        const float bound = (lb[k * kMarchThreads] - lip * at) - lip * away;
         if (__ballot(!(bound > best)) == 0ull) continue;   // (a NaN bound never skips)
         const DevObject &o = S.objects[S.sdfs[k]];
         const int kind = o.kind;
         if (kind == RT_TRIANGLE || kind == RT_CONE) continue;  // the `_ => {}` arm (:95)
         rc.slot = F.march_slot[k];
         SdfOut d;
-        Sdf<false, false, 2, CACHED>::eval(S, o, ro, rd, t, d, nocnt, rc);
-        lb[k * kMarchThreads] = (d.dist + lip * t) - 2e-3f;
+        if ((F.march_pair >> k) & 1u) {
+            // A Union or Substraction of two leaves: the first child always; the second only if, by its own bound, it can
+            // influence the pair.  Union (src/utils/union.rs:26-42, geometry.rs:46-50): with d2 - d1 >= k the interpolation
+            // factor clamps to 1 and smooth_union returns (d2 * 0 + d1 * 1) - k * 1 * 0, which is 0 + d1 (d2 > 0 whenever d1
+            // is a zero).  Substraction (src/utils/substraction.rs:34): max(-d2, d1) is d1 when d2 > -d1.
+            SdfOut d1;
+            Sdf<false, false, 0, CACHED>::eval(S, S.objects[o.first], ro, rd, t, d1, nocnt, rc);
+            const float lip2 = F.march_lip2[k];
+            const float bound2 = (lb[(n + k) * kMarchThreads] - lip2 * at) - lip2 * away;
+            const float matters_below = kind == RT_UNION ? d1.dist + 0.7f : -d1.dist;
+            if (__ballot(!(bound2 > matters_below)) == 0ull) {
+                d.dist = kind == RT_UNION ? (0.0f + d1.dist) - 0.0f : d1.dist;
+            } else {
+                rc.slot = F.march_slot2[k];
+                SdfOut d2;
+                Sdf<false, false, 0, CACHED>::eval(S, S.objects[o.second], ro, rd, t, d2, nocnt, rc);
+                if (UPDATE) lb[(n + k) * kMarchThreads] = (d2.dist + lip2 * t) - 2e-3f;
+                d.dist = kind == RT_UNION ? rt_smooth_union(d1.dist, d2.dist, 0.7f) : rt_max(-d2.dist, d1.dist);
+            }
+        } else {
+            Sdf<false, false, 2, CACHED>::eval(S, o, ro, rd, t, d, nocnt, rc);
+        }
+        if (UPDATE) lb[k * kMarchThreads] = (d.dist + lip * t) - 2e-3f;
         if (d.dist < best) best = d.dist;
     }
     return best;
@@ -1170,7 +1194,7 @@ RT_DEV void rm_fill_cache(const DevScene &S, f3 ro, f3 rd, RayCache &rc) {
 // CACHE: the march loop reads the leaves' object-space rays from LDS (dynamic LDS: n_leaf_slots * 3 * (kMarchThreads + 1)
 // floats); chosen by the host when the scene's leaf count fits.  Launched with kMarchThreads threads per workgroup.
 // SKIP (timed variant only, at most 8 entries in Scene.sdfs): march steps evaluate only the entries that can hold the
-// minimum (rm_sdfs_march; dynamic LDS: n_sdfs * kMarchThreads more floats behind the ray cache).
+// minimum (rm_sdfs_march; dynamic LDS: 2 * n_sdfs * kMarchThreads more floats behind the ray cache).
 template <bool EVENTS, bool CACHE, bool SKIP = false>
 __global__ void __launch_bounds__(256, 8) rt_march_kernel(const DevScene S, const DevCamera C, const DevFrame F) {
     extern __shared__ float s_ray[];
@@ -1207,12 +1231,12 @@ __global__ void __launch_bounds__(256, 8) rt_march_kernel(const DevScene S, cons
         float t = 0.0f, t_eval = 0.0f;
         bool hit = false;
         float *lb = s_ray + F.leaf_slots * (3u * kMarchThreads + 3u) + threadIdx.x;   // behind the ray cache
-        if (SKIP) for (uint32_t k = 0; k < S.n_sdfs; k++) lb[k * kMarchThreads] = -RT_F32_MAX;   // nothing evaluated yet
+        if (SKIP) for (uint32_t k = 0; k < 2u * S.n_sdfs; k++) lb[k * kMarchThreads] = -RT_F32_MAX;   // nothing evaluated yet (entries, then second children)
         for (int i = 0; i < 255; i++) {
             if (t > 40.0f) break;
             cnt.add(RT_CNT_MARCH_STEP);
             SdfOut d;
-            if (SKIP) d.dist = rm_sdfs_march<CACHE>(S, F, ro, rd, t, rc, lb);
+            if (SKIP) d.dist = rm_sdfs_march<CACHE, true>(S, F, ro, rd, t, rc, lb, t, 0.0f);
             else rm_sdfs<EVENTS, false, CACHE>(S, ro, rd, t, d, cnt, rc);
             t_eval = t;
             t = t + d.dist;
@@ -1225,6 +1249,9 @@ __global__ void __launch_bounds__(256, 8) rt_march_kernel(const DevScene S, cons
             const uint32_t obj_idx = rm_sdfs<false, true, CACHE>(S, ro, rd, t_eval, rh, nocnt, rc);
             const float distance = t;
             f3 hitp = ro + rd * distance;
+            // distance of hitp from the camera ray's point at t_eval, where the bounds of rm_sdfs_march are valid (the last step
+            // may have been negative; |rd| is 1 up to rounding)
+            const float last_step = rt_abs(distance - t_eval) * 1.001f + 1e-6f;
             // normal (:109-139)
             const float k = 0.5773f * 0.0005f;
             const f3 xyy = mk3(1.0f, -1.0f, -1.0f), yyx = mk3(-1.0f, -1.0f, 1.0f), yxy = mk3(-1.0f, 1.0f, -1.0f), xxx = mk3(1.0f, 1.0f, 1.0f);
@@ -1234,7 +1261,8 @@ __global__ void __launch_bounds__(256, 8) rt_march_kernel(const DevScene S, cons
             for (int tap = 0; tap < 4; tap++) {
                 const f3 e = tap == 0 ? xyy : (tap == 1 ? yyx : (tap == 2 ? yxy : xxx));
                 SdfOut a;
-                rm_sdfs<EVENTS, false>(S, hitp, e, k, a, cnt, rc);
+                if (SKIP) a.dist = rm_sdfs_march<false, false>(S, F, hitp, e, k, rc, lb, t_eval, last_step + 0.000501f);   // |e| k = 0.0005
+                else rm_sdfs<EVENTS, false>(S, hitp, e, k, a, cnt, rc);
                 const f3 term = e * a.dist;
                 nsum = tap == 0 ? term : nsum + term;
             }
@@ -1278,7 +1306,8 @@ __global__ void __launch_bounds__(256, 8) rt_march_kernel(const DevScene S, cons
                 cnt.add(RT_CNT_OCCLUSION_TAP);
                 float hr = 0.02f + 0.025f * (float)(i * i);
                 SdfOut dd;
-                rm_sdfs<EVENTS, false>(S, hitp, n, hr, dd, cnt, rc);
+                if (SKIP) dd.dist = rm_sdfs_march<false, false>(S, F, hitp, n, hr, rc, lb, t_eval, last_step + hr * 1.001f);   // |n| = 1
+                else rm_sdfs<EVENTS, false>(S, hitp, n, hr, dd, cnt, rc);
                 occ = occ + (-(dd.dist - hr)) * sca;
                 sca = sca * 0.85f;
             }

@@ -772,8 +772,8 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
 
     DevFrame F;
     F.frame_index = p->frame_index; F.row_begin = rb; F.row_end = re; F.tile_row_step = 8u * stride; F.leaf_slots = 0; F.accumulate = p->accumulate; F.seed = p->seed;
-    F.march_skip = 0u;
-    for (int k = 0; k < 8; k++) { F.march_lip[k] = 0.0f; F.march_slot[k] = 0u; }
+    F.march_skip = 0u; F.march_pair = 0u;
+    for (int k = 0; k < 8; k++) { F.march_lip[k] = 0.0f; F.march_slot[k] = 0u; F.march_lip2[k] = 0.0f; F.march_slot2[k] = 0u; }
     F.skip_accum_store = (!p->accumulate && (p->flags & RT_RENDER_SKIP_ACCUM_STORE)) ? 1 : 0;
     F.rgba = d_rgba8 ? (uint32_t *)d_rgba8 : c->rgba.ptr;
     F.accum = d_accum ? (float *)d_accum : c->accum.ptr;
@@ -885,6 +885,17 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
                 if ((double)F.march_lip[k] < rate) F.march_lip[k] = std::nextafter(F.march_lip[k], HUGE_VALF);
                 F.march_slot[k] = slot;
                 const int kind = c->h_objects[idx].kind;
+                if (kind == RT_UNION || kind == RT_SUBSTRACTION) {   // a pair of leaves: the second child gets a bound of its own
+                    const rt_object &pair = c->h_objects[idx];
+                    auto leaf = [&](int32_t i) { const int kk = c->h_objects[(size_t)i].kind; return kk == RT_SPHERE || kk == RT_CUBOID || kk == RT_CYLINDER || kk == RT_PLANE; };
+                    if (leaf(pair.first) && leaf(pair.second)) {
+                        const double r2 = march_fall_rate(c->h_objects, (uint32_t)pair.second, 0) * 1.001;
+                        F.march_lip2[k] = (float)r2;
+                        if ((double)F.march_lip2[k] < r2) F.march_lip2[k] = std::nextafter(F.march_lip2[k], HUGE_VALF);
+                        F.march_slot2[k] = slot + ((cache && c->h_objects[(size_t)pair.first].kind != RT_PLANE) ? 1u : 0u);
+                        F.march_pair |= 1u << k;
+                    }
+                }
                 if (cache && kind != RT_TRIANGLE && kind != RT_CONE) {
                     rt_scene_desc d1;
                     std::memset(&d1, 0, sizeof(d1));
@@ -895,7 +906,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         }
         F.march_skip = skip ? 1u : 0u;
         if (skip) {
-            lds += (size_t)S.n_sdfs * threads * sizeof(float);
+            lds += (size_t)2u * S.n_sdfs * threads * sizeof(float);
             if (cache) launch(rt_march_kernel<false, true, true>, grid, threads, lds, s, S, cam, F);
             else launch(rt_march_kernel<false, false, true>, grid, threads, lds, s, S, cam, F);
         } else if (cache) {
