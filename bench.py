@@ -36,6 +36,8 @@ import subprocess
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -345,6 +347,9 @@ def main() -> None:
             r1, s1 = count_step(warmup)
             rays_timed, sky_timed = r1 * steps, s1 * steps
         rays_rank = rays_timed // steps
+        # launches of the render kernel issued after the timed steps (tools/summarize_profile.py picks the timed ones out of a
+        # kernel trace by counting back from the end)
+        launches_after = (N_POSES if motion else 1) * (1 if chained else len(sample_ids(warmup))) + (1 if chained else (1 + min(8, launches_per_step) if batched else 0))
 
         # the same frames with the reference's write of the linear value to Renderer.accumulated (src/renderer.rs:68) left in
         ms_with_store = None
@@ -360,6 +365,7 @@ def main() -> None:
             q1.record(stream)
             torch.cuda.synchronize()
             ms_with_store = q0.elapsed_time(q1) / k2
+            launches_after += 10 + k2
 
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         r = torch.tensor([float(rays_timed), float(sky_timed)], dtype=torch.float64, device="cuda")
@@ -410,7 +416,7 @@ def main() -> None:
                            "rays_per_step_per_rank": int(rays_rank), "traced_rays_per_step": int(round((rays_all - sky_all) / steps)),
                            "untraced_rays_per_step": int(round(sky_all / steps)), "sharding": shard, "clock_prewarm_ms": int(CLOCK_PREWARM_S * 1e3),
                            "accumulator_store": "n/a (accumulating)" if accumulate or shard == "samples" else ("skipped" if skip_store else "written"),
-                           "sky_tiles": sky_tiles,
+                           "sky_tiles": sky_tiles, "render_launches_after_timed_steps": launches_after,
                            "ranks": world, "backend": backend if use_dist else "none", "exchange_ms_per_step": round(exchange_ms, 4),
                            "collective": ("none" if shard in ("none", "frames") or not xch.collectives else
                                           "all_gather(rgba8 tile rows)" if shard == "rows" else
@@ -538,37 +544,47 @@ def cpu_baseline(pkg, scene, width, height, accumulate) -> dict:
     tex = scene.textures()
     # Camera.ray_directions is computed once per camera change in the reference (src/camera.rs:128-157), outside the frames
     dirs = orc.ray_directions(cam)
-    # bounded sample: evenly spaced 8-row bands covering ~1/6 of the frame (all of it for cheap scenes), about 10-30 s of core time
-    budget_rows = height if not scene.desc.ray_marching and scene.desc.n_objects < 100 else max(8, height // 48)
-    n_bands = max(1, budget_rows // 8)
-    starts = [int(round(i * (height - 8) / max(1, n_bands - 1))) // 8 * 8 for i in range(n_bands)] if n_bands * 8 < height else None
+    # Bounded sample: whole frames (the oracle deals the reference's 200 chunks to `threads` workers) when a frame takes the
+    # cores a few seconds at most; otherwise evenly spaced single rows, one worker thread per row at a time, as many rows as
+    # make one pass take about four seconds (calibrated on the frame's middle row)
+    from concurrent.futures import ThreadPoolExecutor
+    shared_accum = np.zeros((height, width, 4), dtype=np.float32)
+
+    def row(y: int) -> int:
+        r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=1, want_counters=True, rows=(y, y + 1), ray_dirs=dirs, accum=shared_accum)
+        return sum(r["counters"][:5])
+
+    t0 = time.perf_counter()
+    row(height // 2)
+    t_row = max(time.perf_counter() - t0, 1e-5)
+    n_rows = int(max(threads, min(height, round(4.0 * threads / t_row))))
+    starts = None if n_rows >= height else sorted({int((i + 0.5) * height / n_rows) for i in range(n_rows)})
+    pool = ThreadPoolExecutor(max_workers=threads) if starts is not None else None
+
     def one_pass():
         """(rays, seconds) of one pass over the sample."""
         t0 = time.perf_counter()
-        rays = 0
         if starts is None:
             r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, want_counters=True, ray_dirs=dirs)
             rays = sum(r["counters"][:5])
         else:
-            for y in sorted(set(starts)):
-                r = orc.render(scene.desc, cam, tex, accumulate=accumulate, n_threads=threads, want_counters=True, rows=(y, y + 8), ray_dirs=dirs)
-                rays += sum(r["counters"][:5])
+            rays = sum(pool.map(row, starts))
         return rays, time.perf_counter() - t0
 
     one_pass()   # warm-up (page faults, thread start)
-    # repeated until the cores have worked for about 20 core-seconds, at least five times: the value is the median pass
+    # repeated for about twelve seconds, at least five times: the value is the median pass
     rates, rays_all, t_all = [], 0, 0.0
-    while len(rates) < 5 or (t_all * threads < 20.0 and len(rates) < 200):
+    while len(rates) < 5 or (t_all < 12.0 and len(rates) < 200):
         rays, dt = one_pass()
         rates.append(rays / dt / 1e6)
         rays_all += rays
         t_all += dt
     rates.sort()
     median = rates[len(rates) // 2] if len(rates) % 2 else 0.5 * (rates[len(rates) // 2 - 1] + rates[len(rates) // 2])
-    what = f"full {width}x{height} frames" if starts is None else f"passes over {len(set(starts))} evenly spaced 8-row bands of the {width}x{height} frame"
+    what = f"full {width}x{height} frames" if starts is None else f"passes over {len(starts)} evenly spaced rows of the {width}x{height} frame"
     return {"value": round(median, 3), "unit": "Mrays/s", "cores": threads, "kind": "port", "min": round(rates[0], 3), "max": round(rates[-1], 3),
             "repeats": len(rates),
-            "sample": f"{len(rates)} {what}: median {median:.1f}, min {rates[0]:.1f}, max {rates[-1]:.1f} Mrays/s; {rays_all} rays in {t_all:.2f} s; "
+            "sample": f"{len(rates)} {what}: median {median:.4g}, min {rates[0]:.4g}, max {rates[-1]:.4g} Mrays/s; {rays_all} rays in {t_all:.2f} s; "
                       "CPU restatement of the reference (Rust toolchain unavailable)"}
 
 

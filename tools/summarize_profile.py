@@ -27,16 +27,19 @@ def main():
                        f"{r.get('LDS_Block_Size')}, {r.get('Scratch_Size')}, {r.get('Grid_Size')}, {r.get('Workgroup_Size')}")
         # the timed steps of bench.py are the last `steps` dispatches of the render kernel before the counting variant's
         # single dispatch; the ones before them are the clock pre-warm and the warm-up steps
+        after = 1
         try:
-            steps = json.load(open(os.path.join(d, "bench_under_trace.json")))["steps"]
+            line = json.load(open(os.path.join(d, "bench_under_trace.json")))
+            steps = line["steps"] * (1 if "rt_wf_chain" in line["roofline"]["kernel"] else line["config"]["samples_per_step"])
+            after = int(line["config"].get("render_launches_after_timed_steps", 1))
         except (OSError, ValueError, KeyError):
             steps = None
         if steps:
             for k, v in by.items():
-                if "rt_" in k and "<false" in k and len(v) > steps:
+                if "rt_" in k and ("<false" in k or "rt_wf_chain" in k or "rt_wf_diffuse" in k or "rt_refill" in k) and len(v) >= steps + after:
                     v.sort(key=lambda x: int(x[1]["Start_Timestamp"]))
-                    timed = [x[0] for x in v[-(steps + 1):-1]]   # the very last one is bench.py's untimed ray-count pass
-                    out.append(f"== timed steps only: {k[:90]}: last {len(timed)} dispatches before the final one, mean {sum(timed) / len(timed):.0f} ns, "
+                    timed = [x[0] for x in v[-(steps + after):-after]]   # behind them: bench.py's untimed passes (ray counts, store variant)
+                    out.append(f"== timed steps only: {k[:90]}: {len(timed)} dispatches, {after} more of the kernel behind them, mean {sum(timed) / len(timed):.0f} ns, "
                                f"min {min(timed)}, max {max(timed)}")
     for f in sorted(glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
         rows = list(csv.DictReader(open(f)))
