@@ -829,7 +829,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         }
 #endif
     } else if (regroup) {
-        hipLaunchKernelGGL(rt_wf_order_kernel, dim3(1), dim3(256), 0, s, W.ctrl, W.tiles_x, W.tiles_y, grid.x);
+        hipLaunchKernelGGL(rt_wf_order_kernel, dim3(1), dim3(kWfOrderThreads), 0, s, W.ctrl, W.tiles_x, W.tiles_y, grid.x);
 #ifdef RT_WF_STATS
         static unsigned long long *s_wfstats = nullptr;
         if (!s_wfstats) (void)hipMalloc((void **)&s_wfstats, 2 * WS_N * sizeof(unsigned long long));

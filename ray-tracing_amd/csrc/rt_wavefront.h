@@ -758,28 +758,57 @@ __global__ void __launch_bounds__(64, 8) rt_refill_diffuse_kernel(const DevScene
 // still to be handed out divided by the number of wavefronts; going down the launch order, the item size of a row is the
 // largest one for which that holds (by the previous launch's rays per row; uniform rows without history), and it never grows
 // again.  How small items may get depends on how many whole tiles there are per wavefront (see max_cls below).
-constexpr uint32_t kWfMaxOrderRows = 8192u;
+// All of it runs in parallel over the rows (the kernel stands in front of every launch: done by one thread it took 54 us
+// of a 1.4 ms sample at 4K): prefix sums by chunks and a scan of the chunk sums, the cheapest window by an atomic minimum,
+// and -- because the size class along the launch order only ever grows -- the first row of every class as the minimum over
+// the rows whose own comparison asks for at least that class.
+constexpr uint32_t kWfMaxOrderRows = 4096u;   // taller frames run top-down with uniform rows
+constexpr uint32_t kWfOrderThreads = 256u;
 #ifndef RT_WF_GUIDE
 #define RT_WF_GUIDE 1.0f     // safety factor on an item's work in that comparison
 #endif
-__global__ void __launch_bounds__(256) rt_wf_order_kernel(uint32_t *ctrl, uint32_t tiles_x, uint32_t tiles_y, uint32_t groups) {
-    __shared__ uint32_t s_pre[kWfMaxOrderRows + 1u];
+// exclusive prefix of v over the workgroup's threads; s_wave holds one word per wavefront
+__device__ __forceinline__ uint32_t wf_order_scan(uint32_t v, uint32_t *s_wave) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t x = v;
+#pragma unroll
+    for (uint32_t off = 1u; off < 64u; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+    if (lane == 63u) s_wave[threadIdx.x >> 6] = x;
+    __syncthreads();
+    uint32_t base = 0u;
+    for (uint32_t w = 0u; w < (threadIdx.x >> 6); w++) base += s_wave[w];
+    __syncthreads();
+    return base + x - v;
+}
+__global__ void __launch_bounds__(kWfOrderThreads) rt_wf_order_kernel(uint32_t *ctrl, uint32_t tiles_x, uint32_t tiles_y, uint32_t groups) {
+    __shared__ uint32_t s_pre[kWfMaxOrderRows + 1u];    // s_pre[r]: rays of the rows before r
+    __shared__ uint32_t s_work[kWfMaxOrderRows + 1u];   // the same over max(rays, 1): the work a row stands for
+    __shared__ uint32_t s_wave[kWfOrderThreads / 64u];
     __shared__ unsigned long long s_best;
-    __shared__ uint32_t s_offset;
+    __shared__ uint32_t s_offset, s_first[4];
     const uint32_t T = tiles_y, L = (T * 3u) / 8u;
     const bool history = T <= kWfMaxOrderRows;
-    if (threadIdx.x == 0u) s_offset = 0u;
+    if (threadIdx.x == 0u) { s_offset = 0u; s_best = ~0ull; s_first[0] = 0u; s_first[1] = T; s_first[2] = T; s_first[3] = T; }
+    uint32_t total = 0u;
     if (history) {
-        if (threadIdx.x == 0u) {
-            uint32_t acc = 0u;
-            s_pre[0] = 0u;
-            for (uint32_t r = 0; r < T; r++) { acc += ctrl[kWfCtrlRows + r]; s_pre[r + 1u] = acc; }
-            s_best = ~0ull;
-        }
+        for (uint32_t r = threadIdx.x; r < T; r += kWfOrderThreads) s_pre[r + 1u] = ctrl[kWfCtrlRows + r];
         __syncthreads();
-        const uint32_t total = s_pre[T];
+        const uint32_t chunk = (T + kWfOrderThreads - 1u) / kWfOrderThreads;
+        const uint32_t r0 = min(threadIdx.x * chunk, T), r1 = min(r0 + chunk, T);
+        uint32_t a = 0u, b = 0u;
+        for (uint32_t r = r0; r < r1; r++) { const uint32_t w = s_pre[r + 1u]; a += w; b += w > 0u ? w : 1u; }
+        a = wf_order_scan(a, s_wave);
+        b = wf_order_scan(b, s_wave);
+        for (uint32_t r = r0; r < r1; r++) {
+            const uint32_t w = s_pre[r + 1u];
+            a += w; b += w > 0u ? w : 1u;
+            s_pre[r + 1u] = a; s_work[r + 1u] = b;
+        }
+        if (threadIdx.x == 0u) { s_pre[0] = 0u; s_work[0] = 0u; }
+        __syncthreads();
+        total = s_pre[T];
         if (total != 0u && L > 0u) {
-            for (uint32_t s0 = threadIdx.x; s0 < T; s0 += blockDim.x) {   // window [s0, s0 + L), wrapping
+            for (uint32_t s0 = threadIdx.x; s0 < T; s0 += kWfOrderThreads) {   // window [s0, s0 + L), wrapping
                 const uint32_t e = s0 + L;
                 const uint32_t sum = e <= T ? s_pre[e] - s_pre[s0] : (total - s_pre[s0]) + s_pre[e - T];
                 atomicMin(&s_best, ((unsigned long long)sum << 32) | s0);
@@ -789,37 +818,32 @@ __global__ void __launch_bounds__(256) rt_wf_order_kernel(uint32_t *ctrl, uint32
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0u) {
-        const uint32_t offset = s_offset;
-        const bool costs = history && s_pre[T] != 0u;
-        // work of launch-order row k and of the rows from k on
-        auto row_work = [&](uint32_t k) -> float {
-            if (!costs) return 1.0f;
-            uint32_t r = k + offset; if (r >= T) r -= T;
-            const uint32_t w = s_pre[r + 1u] - s_pre[r];
-            return (float)(w > 0u ? w : 1u);
-        };
-        float remaining = 0.0f;
-        for (uint32_t k = 0; k < T; k++) remaining += row_work(k);
-        // smallest item size allowed: halves below four whole tiles per wavefront, quarters below one, eighths below a quarter
-        // (measured on the 10 000-sphere frame: at 4K, 2.3 tiles per wavefront, halves gain 10 % and quarters 5 %; at 8K, 9 tiles
-        // per wavefront, every smaller size loses 1-3 %: short pools drain at low occupancy)
-        const uint32_t n_tiles = tiles_x * T;
-        const uint32_t max_cls = n_tiles >= 4u * groups ? 0u : (n_tiles >= groups ? 1u : (4u * n_tiles >= groups ? 2u : 3u));
-        uint32_t first_row[4] = {0u, T, T, T};   // first launch-order row of each size class
-        uint32_t cls = 0u;
-        for (uint32_t k = 0; k < T; k++) {
-            const float w = row_work(k);
-            const float item = RT_WF_GUIDE * (float)groups * w / (float)tiles_x;   // groups x (work of one whole tile of this row)
-            while (cls < max_cls && item > remaining * (float)(1u << cls)) { cls++; first_row[cls] = k; }
-            remaining -= w;
+    const uint32_t offset = s_offset;
+    const bool costs = history && total != 0u;
+    // smallest item size allowed: halves below four whole tiles per wavefront, quarters below one, eighths below a quarter
+    // (measured on the 10 000-sphere frame: at 4K, 2.3 tiles per wavefront, halves gain 10 % and quarters 5 %; at 8K, 9 tiles
+    // per wavefront, every smaller size loses 1-3 %: short pools drain at low occupancy)
+    const uint32_t n_tiles = tiles_x * T;
+    const uint32_t max_cls = n_tiles >= 4u * groups ? 0u : (n_tiles >= groups ? 1u : (4u * n_tiles >= groups ? 2u : 3u));
+    for (uint32_t k = threadIdx.x; k < T && max_cls > 0u; k += kWfOrderThreads) {   // k: position in the launch order
+        uint32_t w = 1u, remaining = T - k;   // work of row k and of the rows from k on
+        if (costs) {
+            const uint32_t r = k + offset < T ? k + offset : k + offset - T;
+            w = s_work[r + 1u] - s_work[r];
+            remaining = k + offset < T ? (s_work[T] - s_work[r]) + s_work[offset] : s_work[offset] - s_work[r];
         }
-        const uint32_t r1 = first_row[1], r2 = first_row[2], r3 = first_row[3];
+        const float item = RT_WF_GUIDE * (float)groups * (float)w / (float)tiles_x;   // groups x (work of one whole tile of this row)
+        uint32_t cls = 0u;
+        while (cls < max_cls && item > (float)remaining * (float)(1u << cls)) cls++;
+        for (uint32_t c = 1u; c <= cls; c++) atomicMin(&s_first[c], k);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        const uint32_t r1 = s_first[1], r2 = s_first[2], r3 = s_first[3];   // first launch-order row of each size class
         const uint32_t i0 = r1 * tiles_x, i1 = i0 + (r2 - r1) * tiles_x * 2u, i2 = i1 + (r3 - r2) * tiles_x * 4u, i3 = i2 + (T - r3) * tiles_x * 8u;
         ctrl[kWfCtrlNext] = 0u; ctrl[kWfCtrlRowOffset] = offset;
         ctrl[kWfCtrlItems0] = i0; ctrl[kWfCtrlItems1] = i1; ctrl[kWfCtrlItems2] = i2; ctrl[kWfCtrlItems3] = i3;
         ctrl[kWfCtrlTile2] = r2 * tiles_x; ctrl[kWfCtrlTile3] = r3 * tiles_x;
     }
-    __syncthreads();
     for (uint32_t r = threadIdx.x; r < T; r += blockDim.x) ctrl[kWfCtrlRows + r] = 0u;
 }
