@@ -305,7 +305,10 @@ int32_t rt_render_device(rt_ctx *ctx, const rt_render_params *params, void *d_rg
  * e.g. 1280x720), otherwise RT_ERR_UNSUPPORTED.  d_rgba8 / d_accum NULL select the context's own buffers, which
  * rt_set_camera allocated earlier.  All calls on one GPU share the array (the kernels overwrite every row they own, so
  * nothing needs clearing between calls): launches that overlap on one GPU -- two contexts, or two streams -- race on it,
- * and rt_get_stats must be read before the next such launch. */
+ * and rt_get_stats must be read before the next such launch.  The other device buffers a launch may want -- the pools of the
+ * path tracer that re-groups rays, the sky words of the tile classification -- are used when an earlier rt_render_device
+ * launch of this shape has left them in the context, and done without otherwise (one lane per pixel, no classification:
+ * slower, the same pixels). */
 int32_t rt_render_device_noalloc(rt_ctx *ctx, const rt_render_params *params, void *d_rgba8, void *d_accum, void *stream);
 
 /* sample_count accumulating frames in one call: frame_index = params->frame_index, +1, ..., the pixels, accumulator and frame

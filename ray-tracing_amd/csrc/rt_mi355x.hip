@@ -688,9 +688,12 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
     const uint64_t n_waves = (uint64_t)blocks * waves_per_block;  // diagnostic builds size their table by it
     (void)n_waves;
     // Large diffuse scenes without refractive materials: persistent wavefronts that re-group their rays between bounces
-    // (rt_wavefront.h).  The counting variant, the no-alloc entry point and the A/B flag keep the one-lane-per-pixel kernel.
-    const bool regroup = !S.ray_marching && S.bvh2_nodes && S.diffuse && !c->has_refractive && maxd >= 1u && !events && !noalloc &&
-                         !(p->flags & RT_RENDER_ONE_LANE_PER_PIXEL);
+    // (rt_wavefront.h).  The counting variant and the A/B flag keep the one-lane-per-pixel kernel, and so does the no-alloc
+    // entry point unless the pools an earlier rt_render_device launch of this shape allocated are there to be used.
+    const bool wf_buffers_fit = c->wf_groups != 0u && c->wf_pool.cap >= (size_t)c->wf_groups * kWfPool * 4u &&
+                                c->wf_ctrl.cap >= (size_t)kWfCtrlRows + tiles_y;
+    const bool regroup = !S.ray_marching && S.bvh2_nodes && S.diffuse && !c->has_refractive && maxd >= 1u && !events &&
+                         (!noalloc || wf_buffers_fit) && !(p->flags & RT_RENDER_ONE_LANE_PER_PIXEL);
     // Small diffuse scenes (linear scan) without refractive materials: lanes take the strip's next pixel when their path ends
     const bool refill = !regroup && !S.ray_marching && !S.bvh_nodes && S.diffuse && !c->has_refractive && maxd >= 1u && !events &&
                         !(p->flags & RT_RENDER_ONE_LANE_PER_PIXEL);
@@ -782,8 +785,9 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
     F.tile_sky = nullptr;
     // Sky tiles for the linear-scan trace kernels: classified once per (scene, camera, rows of the launch), on the launch's
     // stream ahead of the first render that needs them; every later launch over the same rows reuses the words.
-    const bool sky_tiles = !regroup && !refill && !S.ray_marching && !S.bvh_nodes && !c->has_refractive && !events && !noalloc && maxd >= 1u &&
-                           S.n_objects >= 1u &&
+    // (the no-alloc entry point: only with the words and the event of an earlier launch of this shape in place)
+    const bool sky_tiles = !regroup && !refill && !S.ray_marching && !S.bvh_nodes && !c->has_refractive && !events && maxd >= 1u &&
+                           (!noalloc || (c->tile_sky.cap >= blocks && c->tile_sky_done != nullptr)) && S.n_objects >= 1u &&
                            !(p->flags & RT_RENDER_NO_SKY_TILES);
     if (sky_tiles) {
         const uint64_t k0 = ((uint64_t)c->scene_serial << 32) | ((uint64_t)c->camera.width << 16) | (uint64_t)c->camera.height;

@@ -54,6 +54,35 @@ def test_noalloc_entry_point_equals_render_device_on_two_calls_in_a_row(pkg):
         ctx.stats()
         torch.cuda.synchronize()
         assert torch.cuda.mem_get_info()[0] == free_before, "rt_render_device_noalloc changed the amount of free device memory"
+        # with the words of an earlier rt_render_device launch of this shape in place, the entry point renders with the sky
+        # classification too (before such a launch it renders without): same frame either way, still no allocation
+        assert ctx.hierarchy_info()["classified_workgroups"] > 0
+        # a large diffuse scene: the one-lane-per-pixel kernel before rt_render_device has allocated the path tracer's pools,
+        # the re-grouping kernel after; both leave rt_render_device's frame, accumulator and ray count
+        s = pkg.Scene("spheres1k"); s.desc.max_ray_bounces = 4
+        fresh = pkg.Context(0)
+        try:
+            fresh.load(s, 320, 200)
+            rgba = torch.zeros((200, 320, 4), dtype=torch.uint8, device="cuda")
+            accum = torch.zeros((200, 320, 4), dtype=torch.float32, device="cuda")
+            frames = []
+            for noalloc in (True, False, True):
+                accum.zero_()
+                torch.cuda.synchronize()
+                free_before = torch.cuda.mem_get_info()[0]
+                rays = 0
+                for f in (1, 2):
+                    fresh.render_device(frame_index=f, accumulate=True, seed=9, noalloc=noalloc, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr())
+                    rays += fresh.stats()["rays_total"]
+                torch.cuda.synchronize()
+                if noalloc:
+                    assert torch.cuda.mem_get_info()[0] == free_before
+                frames.append((rgba.cpu().numpy(), accum.cpu().numpy(), rays))
+            for got in (frames[0], frames[2]):
+                assert np.array_equal(got[0], frames[1][0]) and np.array_equal(got[1].view(np.uint32), frames[1][1].view(np.uint32))
+                assert got[2] == frames[1][2] > 0
+        finally:
+            fresh.close()
         # flag bits the library does not know are refused, by both entry points
         for noalloc in (True, False):
             with pytest.raises(pkg.BackendError, match="unknown bits"):
