@@ -1,10 +1,9 @@
-// Texture ingest for C++ callers: ImageUtils::load_image (src/utils/image.rs:13-29) for the lossless formats.
+// Texture ingest for C++ callers: ImageUtils::load_image (src/utils/image.rs:13-29).
 //
 // The reference decodes any file the `image` crate understands and keeps `into_rgb8()` of it: tightly packed RGB8,
 // alpha dropped, grey replicated.  PNG decoding is lossless, so every correct decoder yields the reference's bytes;
 // that half is implemented here (zlib inflate + the five PNG row filters), together with binary PPM as a
-// decoder-free interchange format.  JPEG output depends on the decoder's IDCT and chroma upsampling, so JPEG files are
-// refused with a message: decode them on the caller's side and attach the RGB8 bytes.
+// decoder-free interchange format.  JPEG files go to rt_jpeg.cpp, which says what can and cannot be matched there.
 #include "rt_host.h"
 
 #include <zlib.h>
@@ -15,6 +14,7 @@
 #include <cstring>
 
 namespace rt {
+bool decode_jpeg(const std::vector<uint8_t> &file, Texture &t, std::string &err);   // rt_jpeg.cpp
 namespace {
 
 uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
@@ -175,8 +175,7 @@ std::string load_image(const std::string &path, Texture &out) {
     bool ok = false;
     if (file.size() >= 8 && file[0] == 0x89 && file[1] == 'P') ok = decode_png(file, t, err);
     else if (file.size() >= 2 && file[0] == 'P' && file[1] == '6') ok = decode_ppm(file, t, err);
-    else if (file.size() >= 2 && file[0] == 0xFF && file[1] == 0xD8)
-        err = "JPEG output depends on the decoder; decode it on the caller's side and attach the RGB8 bytes";
+    else if (file.size() >= 2 && file[0] == 0xFF && file[1] == 0xD8) ok = decode_jpeg(file, t, err);
     else err = "unknown image format";
     if (!ok) return path + ": " + err;
     out = std::move(t);

@@ -1,5 +1,5 @@
 // rt_render_ppm: App3D::run's frame loop (src/app.rs:219-248) without the window, as a command-line program on top of the
-// host mirror: builds one of the reference's demo scenes, attaches textures (PNG / PPM files, in slot order), renders
+// host mirror: builds one of the reference's demo scenes, attaches textures (PNG / JPEG / PPM files, in slot order), renders
 // `frames` frames through Renderer::render -- the scene's update function runs before each frame with ts = frame / 60 --
 // and writes the last frame as a binary PPM.
 //

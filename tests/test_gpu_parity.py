@@ -451,15 +451,7 @@ def test_command_line_driver_of_the_host_mirror(pkg, tmp_path):
     assert os.path.exists(exe), "rt_render_ppm was not built"
     s = pkg.Scene("scene1")
     tex = s.textures()
-    paths = []
-    for i, (name, t) in enumerate(zip(pkg.TEXTURE_FILES, tex)):
-        if name.endswith(".png"):
-            paths.append(os.path.join(pkg.TEXTURE_DIR, name))          # decoded by the C++ loader
-        else:                                                            # JPEG: decoded here, handed over as PPM
-            path = str(tmp_path / f"tex{i}.ppm")
-            with open(path, "wb") as fh:
-                fh.write(b"P6\n%d %d\n255\n" % (t.shape[1], t.shape[0]) + t.tobytes())
-            paths.append(path)
+    paths = [os.path.join(pkg.TEXTURE_DIR, name) for name in pkg.TEXTURE_FILES]   # two PNG, two JPEG: all decoded by the C++ loader
     w, h, frames = 128, 96, 3
     out = str(tmp_path / "frame.ppm")
     r = subprocess.run([exe, "scene1", str(w), str(h), str(frames), out] + paths, capture_output=True, text=True, timeout=100)
