@@ -199,9 +199,10 @@ typedef struct rt_stats {
     uint64_t frames_rendered;
     uint64_t rays_sky_tiles; /* part of rays_total: camera rays of workgroups that the tile classification (see
                               * RT_RENDER_NO_SKY_TILES) gave the value of a miss without tracing them; the reference traces them */
-    uint64_t rays_reused_camera; /* part of rays_total: camera rays of rt_render_samples_device that were not traced because
-                              * the same ray -- Camera.ray_directions[pos] does not change between frames -- was traced for
-                              * the pixel's first sample of the call; the reference traces them in every frame */
+    uint64_t rays_reused_camera; /* part of rays_total: camera rays that were not traced because the same ray --
+                              * Camera.ray_directions[pos] does not change between frames -- was traced for the pixel's first
+                              * sample of an rt_render_samples_device call, or by an earlier frame of the same camera and
+                              * scene (see RT_RENDER_NO_FIRST_HIT_REUSE); the reference traces them in every frame */
 } rt_stats;
 
 /* Arguments of one frame.  Mirrors the per-frame state of Renderer (src/renderer.rs:13-18) as
@@ -245,7 +246,14 @@ typedef enum rt_render_flag {
      * minimum since its last evaluation is left out.  This flag evaluates every entry in every step, as RayMarching::sdfs does
      * (A/B runs and tests that compare the two). */
     RT_RENDER_MARCH_ALL_ENTRIES = 16,
-    RT_RENDER_ALL_FLAGS = 31   /* any other bit in params.flags is refused with RT_ERR_INVALID_ARGUMENT */
+    /* Large diffuse scenes: consecutive frames of one camera and scene (what Renderer accumulates, src/renderer.rs:59-66) trace
+     * the same camera rays -- Camera.ray_directions[pos] is not jittered (src/renderer.rs:49) -- so from the third frame on the
+     * closest hit of every pixel's camera ray (distance and object: 8 bytes per pixel, written by the second frame) is read
+     * back instead of traced again; paths continue from there with the frame's own random numbers.  rt_stats counts such
+     * camera rays in rays_total and in rays_reused_camera.  Any rt_set_scene / rt_update_objects / rt_set_camera, or a launch
+     * over other rows, starts over.  This flag traces every camera ray (A/B runs and tests that compare the two). */
+    RT_RENDER_NO_FIRST_HIT_REUSE = 32,
+    RT_RENDER_ALL_FLAGS = 63   /* any other bit in params.flags is refused with RT_ERR_INVALID_ARGUMENT */
 } rt_render_flag;
 
 /* Creates a context bound to HIP device `device_id` (one context per GPU; one process per GPU

@@ -32,6 +32,7 @@ RT_REFLECTIVE, RT_REFRACTIVE = 0, 1
 RT_DIRECTIONAL, RT_POSITIONAL, RT_SPHERICAL_POSITIONAL = 0, 1, 2
 RT_MATH_POWF, RT_MATH_ATANF, RT_MATH_SQRT = 0, 1, 2
 RT_RENDER_ONE_LANE_PER_PIXEL, RT_RENDER_SKIP_ACCUM_STORE, RT_RENDER_NO_SKY_TILES, RT_RENDER_MARCH_ALL_ENTRIES = 1, 2, 8, 16
+RT_RENDER_NO_FIRST_HIT_REUSE = 32
 
 COUNTER_NAMES = [
     "rays_primary", "rays_reflection", "rays_refraction", "rays_shadow", "rays_march", "raygen",

@@ -84,7 +84,12 @@ struct WfArgs {
     float4 *k0, *k1, *k2;   // what every sample of the slot's pixel shares, from the pixel's camera ray (see the kernel): origin of the
                       // first bounce ray + light x, normal at the first hit + light y, contribution + light z
     uint32_t samples; // accumulating frames this launch renders: frame_index = F.frame_index ... F.frame_index + samples - 1
+    // rt_wf_diffuse_kernel: closest hit of every pixel's camera ray (distance, object | sub << 30 or kWfHitMiss), kept from one
+    // frame to the next of the same camera and scene: trace_ray(camera ray) does not depend on the frame (src/renderer.rs:49)
+    float2 *first_hit;
+    uint32_t first_hit_mode;   // kFirstHitOff / kFirstHitWrite (this launch traces the camera rays and fills the table) / kFirstHitRead
 };
+enum { kFirstHitOff = 0, kFirstHitWrite = 1, kFirstHitRead = 2 };
 
 // pixel of pool slot j in stage 0: sub-tile j / 64, lane-in-tile j % 64 as in lane_pixel
 RT_DEV bool wf_slot_pixel(const DevCamera &C, const DevFrame &F, uint32_t x0, uint32_t y0, uint32_t j, uint32_t &pos) {
@@ -117,7 +122,9 @@ RT_DEV void wf_linear_objects(const DevScene &S, f3 ro, f3 rd, float &closest, i
 // CHAIN (rt_wf_chain_kernel): the pool is the wavefront's array of pixel slots, used in place.  ph[j] = (closest hit among the
 // linear objects, object word) in, (closest hit overall, object word) out; an object word of kWfHitInvalid marks an empty slot,
 // bit kChPrimaryBit a camera ray, whose origin and direction are not stored: pg[j].x is its pixel.
-constexpr uint32_t kChPrimaryBit = 1u << 29, kChObjMask = 0x0FFFFFFFu;
+// kChResultBit: the slot already holds the closest hit of its ray (a camera ray whose hit an earlier frame found, see
+// WfArgs::first_hit): the trace pass leaves it alone, the shade pass takes it like any other result.
+constexpr uint32_t kChPrimaryBit = 1u << 29, kChResultBit = 1u << 28, kChObjMask = 0x0FFFFFFFu;
 RT_DEV uint32_t ch_pack_hit(int best, int best_sub) { return (best < 0 ? kChObjMask : (uint32_t)best) | ((uint32_t)best_sub << 30); }
 template <bool CHAIN = false>
 RT_DEV void wf_trace_pool(const DevScene &S, const DevCamera &C, const DevFrame &F, bool primary, uint32_t n, uint32_t x0, uint32_t y0,
@@ -150,7 +157,7 @@ RT_DEV void wf_trace_pool(const DevScene &S, const DevCamera &C, const DevFrame 
                     if (CHAIN) {
                         h0 = ph[j];
                         const uint32_t hw = __float_as_uint(h0.y);
-                        valid = hw != kWfHitInvalid;
+                        valid = hw != kWfHitInvalid && (hw & kChResultBit) == 0u;
                         if (valid && (hw & kChPrimaryBit)) {
                             ro = ld3(C.position); rd = ld3(C.ray_dirs + 3u * (size_t)pg[j].x);
                         } else if (valid) {
@@ -311,22 +318,31 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_diffuse_kernel(const De
         if (rrow >= W.tiles_y) rrow -= W.tiles_y;
         const uint32_t x0 = tx * kWfTileW + part * (kWfTileW >> cls), y0 = F.row_begin + rrow * F.tile_row_step;
         const uint32_t rays_before = rays;
-        // ---- camera rays against the linear objects, all lanes busy
+        // ---- camera rays against the linear objects, all lanes busy -- or their closest hits as an earlier frame found them
+        const bool known = W.first_hit_mode == kFirstHitRead;
         for (uint32_t base = 0u; base < n_slots; base += 64u) {
             const uint32_t j = base + lane;
             uint32_t pos;
             float closest = RT_F32_MAX;
-            int best = -1, best_sub = 0;
+            uint32_t word = kWfHitInvalid;   // slot outside the frame: never traced, never shaded
             WS_ADD(WS_PREPARE, ~0ull);
-            if (wf_slot_pixel(C, F, x0, y0, j, pos)) wf_linear_objects(S, ld3(C.position), ld3(C.ray_dirs + 3u * (size_t)pos), closest, best, best_sub);
-            else best = (int)kWfHitInvalid;   // slot outside the frame: never traced, never shaded
-            pd[j] = make_float4(1.0f, 1.0f, closest, __uint_as_float(best == (int)kWfHitInvalid ? kWfHitInvalid : wf_pack_hit(best, best_sub)));
+            if (wf_slot_pixel(C, F, x0, y0, j, pos)) {
+                if (known) {
+                    const float2 h = W.first_hit[pos];
+                    closest = h.x; word = __float_as_uint(h.y);
+                } else {
+                    int best = -1, best_sub = 0;
+                    wf_linear_objects(S, ld3(C.position), ld3(C.ray_dirs + 3u * (size_t)pos), closest, best, best_sub);
+                    word = wf_pack_hit(best, best_sub);
+                }
+            }
+            pd[j] = make_float4(1.0f, 1.0f, closest, __uint_as_float(word));
         }
         __syncthreads();
         uint32_t n = n_slots;
         for (uint32_t depth = 0u; depth < maxd && n > 0u; depth++) {
             const bool primary = depth == 0u;
-            wf_trace_pool(S, C, F, primary, n, x0, y0, pa, pb, pd, s_stack, rays WS_PASS);
+            if (!(primary && known)) wf_trace_pool(S, C, F, primary, n, x0, y0, pa, pb, pd, s_stack, rays WS_PASS);
             __syncthreads();
             // ---- shade: color_diffuse at every hit / miss of this bounce (ray_tracing.rs:87-114, :155-157)
             uint32_t out = 0u;
@@ -345,6 +361,7 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_diffuse_kernel(const De
                         (void)wf_slot_pixel(C, F, x0, y0, j, pos);
                         ro = ld3(C.position); rd = ld3(C.ray_dirs + 3u * (size_t)pos);
                         key = rt_rng_path_key(F.seed, pos, F.frame_index);
+                        if (W.first_hit_mode == kFirstHitWrite) W.first_hit[pos] = make_float2(D.z, D.w);
                     } else {
                         const float4 A = pa[j], B = pb[j], Cv = pc[j];
                         ro = mk3(A.x, A.y, A.z); key = __float_as_uint(A.w);
@@ -527,7 +544,10 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_chain_kernel(const DevS
                     ro = mk3(A.x, A.y, A.z); rd = mk3(B.x, B.y, B.z); L = mk3(Cv.x, Cv.y, Cv.z); Cc = mk3(B.w, Cv.w, pd1[j]);
                     key = __float_as_uint(A.w);
                 }
-                if ((hw & kChObjMask) == kChObjMask) {
+                const bool miss = (hw & kChObjMask) == kChObjMask;
+                if (depth == 0u && W.first_hit_mode == kFirstHitWrite)   // (the table's words are the other kernel's: wf_pack_hit)
+                    W.first_hit[pos] = make_float2(H.x, __uint_as_float(miss ? kWfHitMiss : (hw & (kChObjMask | (1u << 30)))));
+                if (miss) {
                     V = L + ambient * Cc;
                     ended = true;
                 } else {
@@ -601,6 +621,7 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_chain_kernel(const DevS
                     respawn = true;
                 }
             }
+            const bool known = W.first_hit_mode == kFirstHitRead;   // the camera rays' closest hits are in the table: none is traced
             if (respawn) {   // the camera ray of this pixel's next frame: only its pixel and its first-hit candidate are stored
                 no = ld3(C.position); nd = ld3(C.ray_dirs + 3u * (size_t)pos);
                 depth = 0u;
@@ -608,8 +629,9 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_chain_kernel(const DevS
             // the next ray against the linear objects (wave-uniform loop: kept outside the divergent code above)
             float nclosest = RT_F32_MAX;
             int nbest = -1, nbest_sub = 0;
-            if (S.n_bvh2_linear != 0u && __ballot(goes_on || respawn) != 0ull) {
-                if (goes_on || respawn) wf_linear_objects(S, no, nd, nclosest, nbest, nbest_sub);
+            const bool to_trace = goes_on || (respawn && !known);
+            if (S.n_bvh2_linear != 0u && __ballot(to_trace) != 0ull) {
+                if (to_trace) wf_linear_objects(S, no, nd, nclosest, nbest, nbest_sub);
             }
             if (goes_on) {
                 pa[j] = make_float4(no.x, no.y, no.z, __uint_as_float(key));
@@ -618,7 +640,14 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_chain_kernel(const DevS
                 pd1[j] = cc.z;
             }
             if (goes_on || respawn) {
-                ph[j] = make_float2(nclosest, __uint_as_float(ch_pack_hit(nbest, nbest_sub) | (respawn ? kChPrimaryBit : 0u)));
+                if (respawn && known) {
+                    const float2 h = W.first_hit[pos];
+                    const uint32_t word = __float_as_uint(h.y);
+                    ph[j] = make_float2(h.x, __uint_as_float((word == kWfHitMiss ? kChObjMask : word) | kChResultBit));
+                    reused += 1u;
+                } else {
+                    ph[j] = make_float2(nclosest, __uint_as_float(ch_pack_hit(nbest, nbest_sub) | (respawn ? kChPrimaryBit : 0u)));
+                }
                 pg[j] = make_uint2(pos, sample | (depth << 24));
             } else if (alive || boot) {
                 ph[j] = make_float2(0.0f, __uint_as_float(kWfHitInvalid));   // no pixel left for this slot

@@ -71,7 +71,7 @@ def test_noalloc_entry_point_equals_render_device_on_two_calls_in_a_row(pkg):
                 torch.cuda.synchronize()
                 free_before = torch.cuda.mem_get_info()[0]
                 rays = 0
-                for f in (1, 2):
+                for f in (1, 2, 3, 4):   # (the fourth reads the camera rays' hits that the third -- the second of its kind -- wrote)
                     fresh.render_device(frame_index=f, accumulate=True, seed=9, noalloc=noalloc, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr())
                     rays += fresh.stats()["rays_total"]
                 torch.cuda.synchronize()
