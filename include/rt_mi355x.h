@@ -249,7 +249,8 @@ typedef enum rt_render_flag {
     /* Large diffuse scenes: consecutive frames of one camera and scene (what Renderer accumulates, src/renderer.rs:59-66) trace
      * the same camera rays -- Camera.ray_directions[pos] is not jittered (src/renderer.rs:49) -- so from the third frame on the
      * closest hit of every pixel's camera ray (distance and object: 8 bytes per pixel, written by the second frame) is read
-     * back instead of traced again; paths continue from there with the frame's own random numbers.  rt_stats counts such
+     * back instead of traced again (single frames: rt_render / rt_render_device); paths continue from there with the frame's
+     * own random numbers.  rt_stats counts such
      * camera rays in rays_total and in rays_reused_camera.  Any rt_set_scene / rt_update_objects / rt_set_camera, or a launch
      * over other rows, starts over.  This flag traces every camera ray (A/B runs and tests that compare the two). */
     RT_RENDER_NO_FIRST_HIT_REUSE = 32,

@@ -709,9 +709,12 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
     }
     if (samples > 1u && !regroup) return fail(c, RT_ERR_STATE, "several samples per launch need the re-grouping path tracer");
     if (samples > kChMaxSamples) return fail(c, RT_ERR_UNSUPPORTED, "more than 2^24 samples in one launch");
+    // Several samples per launch: the kernel with pixel slots.  (Single frames stay with the other kernel also when their
+    // camera rays' hits are known, below: measured at 4K, 1.83 ms in pixel slots against 1.20 ms.)
+    const bool chain = regroup && (samples > 1u || RT_WF_CHAIN_SINGLE != 0);
     WfArgs W = {};
     uint64_t reused_here = 0;   // camera rays of this launch that rt_wf_diffuse_kernel reads from WfArgs::first_hit (it does not count them)
-    if (regroup) {
+    if (regroup && !chain) {
         // camera rays' closest hits from one frame to the next: nothing on the first launch of a (scene, camera, rows), the
         // second writes the table, later ones read it (a camera that moves every frame never pays for the table)
         const uint64_t k0 = ((uint64_t)c->scene_serial << 32) | ((uint64_t)c->camera.width << 16) | (uint64_t)c->camera.height;
@@ -728,10 +731,6 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         }
         if (c->first_hit_launches < 0xFFFFFFFFu) c->first_hit_launches += 1u;
     }
-    // Several samples per launch: the kernel with pixel slots.  (Single frames stay with the other kernel also when their
-    // camera rays' hits are known: measured at 4K, 1.95 ms in pixel slots against 1.20 ms -- a launch of five pixels per slot
-    // is mostly its first and last rounds.)
-    const bool chain = regroup && (samples > 1u || RT_WF_CHAIN_SINGLE != 0);
     if (chain) {
         { const int32_t r = query_wf_groups(c); if (r != RT_OK) return r; }
         W.tiles_x = (c->camera.width + kChTileW - 1u) / kChTileW; W.tiles_y = tiles_y;

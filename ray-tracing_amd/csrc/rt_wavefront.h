@@ -122,9 +122,7 @@ RT_DEV void wf_linear_objects(const DevScene &S, f3 ro, f3 rd, float &closest, i
 // CHAIN (rt_wf_chain_kernel): the pool is the wavefront's array of pixel slots, used in place.  ph[j] = (closest hit among the
 // linear objects, object word) in, (closest hit overall, object word) out; an object word of kWfHitInvalid marks an empty slot,
 // bit kChPrimaryBit a camera ray, whose origin and direction are not stored: pg[j].x is its pixel.
-// kChResultBit: the slot already holds the closest hit of its ray (a camera ray whose hit an earlier frame found, see
-// WfArgs::first_hit): the trace pass leaves it alone, the shade pass takes it like any other result.
-constexpr uint32_t kChPrimaryBit = 1u << 29, kChResultBit = 1u << 28, kChObjMask = 0x0FFFFFFFu;
+constexpr uint32_t kChPrimaryBit = 1u << 29, kChObjMask = 0x0FFFFFFFu;
 RT_DEV uint32_t ch_pack_hit(int best, int best_sub) { return (best < 0 ? kChObjMask : (uint32_t)best) | ((uint32_t)best_sub << 30); }
 template <bool CHAIN = false>
 RT_DEV void wf_trace_pool(const DevScene &S, const DevCamera &C, const DevFrame &F, bool primary, uint32_t n, uint32_t x0, uint32_t y0,
@@ -157,7 +155,7 @@ RT_DEV void wf_trace_pool(const DevScene &S, const DevCamera &C, const DevFrame 
                     if (CHAIN) {
                         h0 = ph[j];
                         const uint32_t hw = __float_as_uint(h0.y);
-                        valid = hw != kWfHitInvalid && (hw & kChResultBit) == 0u;
+                        valid = hw != kWfHitInvalid;
                         if (valid && (hw & kChPrimaryBit)) {
                             ro = ld3(C.position); rd = ld3(C.ray_dirs + 3u * (size_t)pg[j].x);
                         } else if (valid) {
@@ -544,10 +542,7 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_chain_kernel(const DevS
                     ro = mk3(A.x, A.y, A.z); rd = mk3(B.x, B.y, B.z); L = mk3(Cv.x, Cv.y, Cv.z); Cc = mk3(B.w, Cv.w, pd1[j]);
                     key = __float_as_uint(A.w);
                 }
-                const bool miss = (hw & kChObjMask) == kChObjMask;
-                if (depth == 0u && W.first_hit_mode == kFirstHitWrite)   // (the table's words are the other kernel's: wf_pack_hit)
-                    W.first_hit[pos] = make_float2(H.x, __uint_as_float(miss ? kWfHitMiss : (hw & (kChObjMask | (1u << 30)))));
-                if (miss) {
+                if ((hw & kChObjMask) == kChObjMask) {
                     V = L + ambient * Cc;
                     ended = true;
                 } else {
@@ -621,7 +616,6 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_chain_kernel(const DevS
                     respawn = true;
                 }
             }
-            const bool known = W.first_hit_mode == kFirstHitRead;   // the camera rays' closest hits are in the table: none is traced
             if (respawn) {   // the camera ray of this pixel's next frame: only its pixel and its first-hit candidate are stored
                 no = ld3(C.position); nd = ld3(C.ray_dirs + 3u * (size_t)pos);
                 depth = 0u;
@@ -629,9 +623,8 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_chain_kernel(const DevS
             // the next ray against the linear objects (wave-uniform loop: kept outside the divergent code above)
             float nclosest = RT_F32_MAX;
             int nbest = -1, nbest_sub = 0;
-            const bool to_trace = goes_on || (respawn && !known);
-            if (S.n_bvh2_linear != 0u && __ballot(to_trace) != 0ull) {
-                if (to_trace) wf_linear_objects(S, no, nd, nclosest, nbest, nbest_sub);
+            if (S.n_bvh2_linear != 0u && __ballot(goes_on || respawn) != 0ull) {
+                if (goes_on || respawn) wf_linear_objects(S, no, nd, nclosest, nbest, nbest_sub);
             }
             if (goes_on) {
                 pa[j] = make_float4(no.x, no.y, no.z, __uint_as_float(key));
@@ -640,14 +633,7 @@ __global__ void __launch_bounds__(64, RT_WF_WAVES) rt_wf_chain_kernel(const DevS
                 pd1[j] = cc.z;
             }
             if (goes_on || respawn) {
-                if (respawn && known) {
-                    const float2 h = W.first_hit[pos];
-                    const uint32_t word = __float_as_uint(h.y);
-                    ph[j] = make_float2(h.x, __uint_as_float((word == kWfHitMiss ? kChObjMask : word) | kChResultBit));
-                    reused += 1u;
-                } else {
-                    ph[j] = make_float2(nclosest, __uint_as_float(ch_pack_hit(nbest, nbest_sub) | (respawn ? kChPrimaryBit : 0u)));
-                }
+                ph[j] = make_float2(nclosest, __uint_as_float(ch_pack_hit(nbest, nbest_sub) | (respawn ? kChPrimaryBit : 0u)));
                 pg[j] = make_uint2(pos, sample | (depth << 24));
             } else if (alive || boot) {
                 ph[j] = make_float2(0.0f, __uint_as_float(kWfHitInvalid));   // no pixel left for this slot
