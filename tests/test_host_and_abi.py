@@ -260,7 +260,7 @@ def test_host_load_image_refuses_what_it_cannot_decode_exactly(pkg, tmp_path):
 def test_committed_bench_line_carries_the_contract_fields():
     """The benchmark line kept under profiles/ (printed by bench.py on the GPU box) has the fields the harness reads."""
     import json
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_bench_scene3_4k.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_bench_scene3_4k.json")
     d = json.loads(open(path).read().strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -275,6 +275,11 @@ def test_committed_bench_line_carries_the_contract_fields():
     assert abs(d["value"] - d["config"]["rays_per_step_per_rank"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"]
+    assert c["repeats"] >= 5 and c["min"] <= c["value"] <= c["max"]          # the median of repeated passes, with its spread
+    # what was traced and what was not: the two add up to the rays of a step, and the second rate is the first scaled by it
+    cfg = d["config"]
+    assert cfg["traced_rays_per_step"] + cfg["untraced_rays_per_step"] == cfg["rays_per_step_per_rank"]
+    assert abs(d["value_traced_only"] / d["value"] - cfg["traced_rays_per_step"] / cfg["rays_per_step_per_rank"]) < 1e-3
 
 
 def test_command_line_driver_is_built_and_checks_its_arguments(pkg):
