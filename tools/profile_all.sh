@@ -6,6 +6,8 @@ WLS=${@:-scene3_4k scene1_4k tex4_4k scene4_4k scene2_4k spheres10k_4k spheres10
 mkdir -p gpurun_out/bench_$TAG
 for wl in $WLS; do
   bash tools/profile.sh "$TAG" "$wl" > gpurun_out/prof_${TAG}_${wl}.log 2>&1 || { echo "profile of $wl failed"; tail -3 gpurun_out/prof_${TAG}_${wl}.log; exit 1; }
+  # the bench lines below report roofline.traffic from profiles/hbm_traffic.json when its entry was measured on this build
+  python3 tools/update_hbm_traffic.py merge gpurun_out/prof_${TAG}_${wl} > /dev/null || { echo "no traffic entry for $wl"; exit 1; }
   echo "profiled $wl"
 done
 for wl in $WLS; do
