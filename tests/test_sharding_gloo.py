@@ -157,3 +157,47 @@ def test_sample_shards_cover_every_index_once(pkg):
         for world in (1, 2, 3, 8):
             seen = sorted(i for r in range(world) for i in pkg.shard_samples(n, r, world))
             assert seen == list(range(1, n + 1))
+
+
+def _pattern_worker(rank, world, port, out_dir):
+    """Exchange logic alone, at the heights of the benchmark frames: rows of a known pattern instead of rendered ones."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = g.load_package()
+    w = 8
+    ok = True
+    for h in (2160, 4320, 600, 75):
+        want = (torch.arange(h, dtype=torch.int64) * 7 % 251).to(torch.uint8).view(h, 1, 1).expand(h, w, 4)
+        # rows mode: this rank's interleaved tile rows, then one all-gather
+        xch = pkg.FrameExchange(dist, h, w, rank, world, device="cpu", backend="gloo")
+        for b, e in pkg.interleaved_tile_rows(h, rank, world):
+            xch.frame[b:e] = want[b:e]
+        xch.gather_interleaved()
+        ok = ok and bool(torch.equal(xch.frame[:h], want))
+        # samples mode: accumulators summed, owned rows "resolved" (here: the pattern where the sum is right), bands gathered
+        xch = pkg.FrameExchange(dist, h, w, rank, world, device="cpu", backend="gloo")
+        xch.accum.fill_(float(rank + 1))
+        b, e, band = xch.sum_accumulators()
+        ok = ok and bool((band == float(world * (world + 1) // 2)).all()) and band.shape[0] == e - b
+        xch.frame[b:e] = want[b:e]
+        xch.gather_bands(b, e)
+        ok = ok and bool(torch.equal(xch.frame[:h], want))
+    with open(os.path.join(out_dir, f"pattern_{rank}.txt"), "w") as fh:
+        fh.write("ok" if ok else "bad")
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_exchange_shapes_at_the_benchmark_heights_with_more_ranks(tmp_path, world):
+    """FrameExchange with 3 and 4 ranks at 2160, 4320, 600 and 75 rows (270 and 540 tile rows do not divide by 4, 75 rows
+    end in a short tile): the interleaved all-gather and the sum / band gather of the samples mode rebuild every row on
+    every rank."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_pattern_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"pattern_{r}.txt").read() == "ok", f"rank {r}"
