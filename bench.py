@@ -241,7 +241,7 @@ def main() -> None:
             apply_motion(i)
             ids = sample_ids(i)
             if batched and len(ids) > 1:
-                # the samples of a frame in one call: the library overlaps launches of interleaved shares of the rows
+                # the samples of a frame in one call (large diffuse scenes: one launch in which every pixel's samples follow each other)
                 ctx.render_samples_device(ids[0], len(ids), seed=0x5EED, rows=(rows_arg[0], rows_arg[1]) if rows_arg else None,
                                           tile_row_stride=rows_arg[2] if rows_arg else 0, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=sh)
             else:
