@@ -726,8 +726,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         const bool wanted = !(p->flags & RT_RENDER_NO_FIRST_HIT_REUSE) && c->first_hit_launches >= 1u;
         if (wanted && (noalloc ? c->first_hit.cap >= px : c->first_hit.ensure(px) == hipSuccess)) {
             W.first_hit = c->first_hit.ptr;
-            W.first_hit_mode = c->first_hit_filled ? kFirstHitRead : kFirstHitWrite;
-            c->first_hit_filled = true;
+            W.first_hit_mode = c->first_hit_filled ? kFirstHitRead : kFirstHitWrite;   // (marked as filled once the launch is under way, below)
         }
         if (c->first_hit_launches < 0xFFFFFFFFu) c->first_hit_launches += 1u;
     }
@@ -978,6 +977,7 @@ int32_t render_impl(rt_ctx *c, const rt_render_params *p, void *d_rgba8, void *d
         }
     }
     RT_HIP(c, hipGetLastError());
+    if (W.first_hit_mode == kFirstHitWrite) c->first_hit_filled = true;
     if (time_kernel) RT_HIP(c, hipEventRecord(c->ev1, s));
     c->kernel_timed = time_kernel;
     c->last_blocks = blocks * (slot + 1u); c->last_ncnt = ncnt; c->last_events = events; c->timed = true; c->last_stream = s;

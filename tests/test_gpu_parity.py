@@ -621,6 +621,27 @@ def test_regrouping_path_tracer_equals_the_one_lane_per_pixel_kernel(pkg, ctx, n
     assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[0], b[0])
 
 
+@pytest.mark.parametrize("height", [20000, 40000])
+def test_very_tall_frames_through_the_regrouping_path_tracer(pkg, ctx, height):
+    """Frames of 2 500 and 5 000 tile rows: the order kernel in front of rt_wf_diffuse_kernel keeps per-row history for up to
+    4 096 tile rows and hands out taller frames top-down without it.  Three accumulated frames (the second and third with
+    whatever history there is, the third with the camera rays' hits known) equal the one-lane-per-pixel kernel's."""
+    s = pkg.Scene("spheres200")
+    s.desc.max_ray_bounces = 3
+    w = 16
+    ctx.load(s, w, height)
+    got = {}
+    for flags in (0, pkg.RT_RENDER_ONE_LANE_PER_PIXEL):
+        ctx.reset_accum()
+        rays = []
+        for f in (1, 2, 3):
+            ctx.render_device(frame_index=f, accumulate=True, seed=5, flags=flags)
+            rays.append(ctx.stats()["rays_total"])
+        got[flags] = (ctx.read_accum().copy(), rays)
+    assert got[0][1] == got[pkg.RT_RENDER_ONE_LANE_PER_PIXEL][1] and got[0][1][0] >= w * height
+    assert np.array_equal(got[0][0].view(np.uint32), got[pkg.RT_RENDER_ONE_LANE_PER_PIXEL][0].view(np.uint32))
+
+
 def test_camera_ray_hits_kept_between_frames_change_nothing(pkg, orc, ctx):
     """Large diffuse scenes: from the third frame of one (scene, camera, rows) on, rt_wf_diffuse_kernel reads the closest hit of
     every camera ray from the table the second frame wrote instead of tracing it (trace_ray of Camera.ray_directions[pos] does
