@@ -17,6 +17,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _fuzz_seeds(n):
+    """Seeds of a seeded fuzz test: 0 ... n-1, plus RT_FUZZ_EXTRA more when the variable is set (one-off longer campaigns)."""
+    return list(range(n + int(os.environ.get("RT_FUZZ_EXTRA", "0"))))
+
+
 def gpu_frame(ctx, accumulate=False, frame_index=1, seed=0x5EED, reset=True, events=False):
     if reset:
         ctx.reset_accum()
@@ -857,7 +862,7 @@ def test_hierarchy_with_every_primitive_kind_shadows_textures_and_glass(pkg, orc
     assert st["bvh_node"] > 0 and all(cref[k] > 0 for k in ("hit_sphere", "hit_cuboid", "hit_cylinder", "hit_cone", "hit_triangle", "hit_plane", "refraction", "tex_fetch"))
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", _fuzz_seeds(12))
 def test_random_small_scenes_through_the_linear_scan(pkg, orc, ctx, seed):
     """Random scenes of 3-14 objects of every kind (below the hierarchy threshold: linear scan with the wave-level
     bounding-sphere rejection), cameras sometimes inside an object, a directional light whose direction is not unit
@@ -913,7 +918,7 @@ def test_random_small_scenes_through_the_linear_scan(pkg, orc, ctx, seed):
     assert np.array_equal(ctx.read_accum().view(np.uint32), lin.view(np.uint32))
 
 
-@pytest.mark.parametrize("seed", list(range(6)))
+@pytest.mark.parametrize("seed", _fuzz_seeds(6))
 def test_random_scenes_through_the_hierarchy(pkg, orc, ctx, seed):
     """Random scenes of 40-90 bounded objects of every kind plus planes (above the hierarchy threshold), overlapping and
     rotated, with shadows, glass and textures: the hierarchy traversal (timed and counting variants) gives the linear
@@ -1019,7 +1024,7 @@ def test_sky_tile_classification_changes_no_pixel(pkg, orc, ctx, name, size):
     assert np.array_equal(got[0], ref["rgba"]) and np.array_equal(got[1].view(np.uint32), ref["accum"].view(np.uint32)), "moved object"
 
 
-@pytest.mark.parametrize("seed", list(range(6)))
+@pytest.mark.parametrize("seed", _fuzz_seeds(6))
 def test_sky_tile_classification_on_random_scenes_and_cameras(pkg, ctx, seed):
     """The tile classification must never call a tile sky that a camera ray leaves towards an object.  Random small scenes of
     every primitive kind (rotated, tiny and huge, bounded and unbounded planes with unnormalised normals, an object around
@@ -1073,7 +1078,8 @@ def test_sky_tile_classification_on_random_scenes_and_cameras(pkg, ctx, seed):
         assert a[2] == b[2], f"scene {seed} view {view}: ray counts {a[2]} / {b[2]}"
         assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[0], b[0]), f"scene {seed} view {view} (eye {eye}, look {look})"
         sky_seen += ctx.hierarchy_info()["sky_workgroups"]
-    assert sky_seen > 0 or any(o.kind == pkg.RT_PLANE and not o.has_max_dist for o in objs)
+    if seed < 6:   # (the views of an arbitrary extra scene may all be filled by its objects)
+        assert sky_seen > 0 or any(o.kind == pkg.RT_PLANE and not o.has_max_dist for o in objs)
 
 
 @pytest.mark.parametrize("mode", ["whitted", "diffuse"])
@@ -1118,7 +1124,7 @@ def test_unrotated_textured_spheres_on_the_camera_axes(pkg, orc, ctx, mode, many
         assert bool(info["stackless_nodes"]) == many
 
 
-@pytest.mark.parametrize("seed", list(range(8)))
+@pytest.mark.parametrize("seed", _fuzz_seeds(8))
 def test_random_diffuse_scenes_through_the_regrouping_path_tracer(pkg, orc, ctx, seed):
     """Random diffuse (emissive) scenes of 40-90 objects of every primitive kind, rotated and overlapping, with exact
     duplicates (equal distances), planes and a very large sphere (both outside the quantised hierarchy, in its linear
@@ -1204,7 +1210,7 @@ def test_random_diffuse_scenes_through_the_regrouping_path_tracer(pkg, orc, ctx,
     assert_parity(rgba.cpu().numpy(), ref["rgba"], accum.cpu().numpy(), acc, what=f"random diffuse scene {seed}, samples 4-5 continued")
 
 
-@pytest.mark.parametrize("seed", list(range(6)))
+@pytest.mark.parametrize("seed", _fuzz_seeds(6))
 def test_random_scenes_in_the_random_number_modes(pkg, orc, ctx, seed):
     """Diffuse path tracing and the roughness-jitter mode on random small scenes (emissive, glass and plain materials),
     three accumulated samples with a fixed seed: accumulator and bytes equal the oracle's after every sample."""
@@ -1236,7 +1242,8 @@ def test_random_scenes_in_the_random_number_modes(pkg, orc, ctx, seed):
         assert_parity(rgba, ref["rgba"], ctx.read_accum(), acc, what=f"random-mode scene {seed} sample {f}")
     other = ctx.render(frame_index=1, accumulate=True, reset_accum=True, seed=1)
     first = orc.render(sb.desc, cam, (), frame_index=1, accumulate=True, seed=4242 + seed)
-    assert not np.array_equal(other, first["rgba"]), "the seed has no effect"
+    if seed < 6:   # (an arbitrary extra scene may saturate every pixel it does not leave to the sky)
+        assert not np.array_equal(other, first["rgba"]), "the seed has no effect"
 
 
 @pytest.mark.parametrize("name,size", [("scene4", (800, 600)), ("scene4", (333, 77)), ("scene4", (3840, 2160))])
@@ -1270,7 +1277,7 @@ def test_march_steps_that_leave_entries_out_change_no_pixel(pkg, orc, ctx, name,
             assert np.array_equal(got[0][0].view(np.uint32), ref["accum"].view(np.uint32)), f"pose {k} differs from the oracle"
 
 
-@pytest.mark.parametrize("seed", list(range(8)))
+@pytest.mark.parametrize("seed", _fuzz_seeds(8))
 def test_random_sdf_scenes_through_the_march_kernel(pkg, orc, ctx, seed):
     """Random ray-marching scenes: leaves of every kind, Union / Substraction nested up to two levels, random SDF lists
     (with cones and triangles, whose sdf is f32::MAX), textured and plain materials."""
