@@ -501,6 +501,22 @@ def test_full_size_4k_properties(pkg, orc, ctx, name):
         assert_parity(rgba[row:row + 1], ref["rgba"][row:row + 1], a[row:row + 1], ref["accum"][row:row + 1], what=f"{name} 4K row {row}")
 
 
+@pytest.mark.parametrize("name", ["scene3", "tex4", "scene1", "scene4"])
+def test_whole_4k_frame_equals_the_oracle(pkg, orc, ctx, name):
+    """Every pixel of the 3840x2160 frames the benchmark times (BASELINE's 4K configurations: the default scene, the textured
+    scenes, the ray-marched scene; max 5 bounces): RGBA8 bytes and the f32 accumulator against the oracle's whole frame, with
+    the kernels as bench.py launches them (tile classification, march bounds)."""
+    s = pkg.Scene(name)
+    if not s.desc.ray_marching:
+        s.desc.max_ray_bounces = 5
+    w, h = 3840, 2160
+    ctx.load(s, w, h)
+    rgba = ctx.render(frame_index=1, reset_accum=True)
+    acc = ctx.read_accum()
+    ref = orc.render(s.desc, s.camera(w, h), s.textures(), n_threads=16)
+    assert_parity(rgba, ref["rgba"], acc, ref["accum"], what=f"{name} whole 4K frame")
+
+
 @pytest.mark.parametrize("name", ["scene3", "tex4"])
 def test_bench_configuration_at_4k_equals_the_unclassified_frame(pkg, orc, ctx, name):
     """The exact configuration bench.py times -- 3840x2160, tile classification on, RT_RENDER_SKIP_ACCUM_STORE -- against the
@@ -818,6 +834,54 @@ def test_ten_thousand_sphere_scene_at_full_size_properties(pkg, orc, ctx):
     assert abs(float(a[..., :3].mean()) / float(acc[..., :3].mean() / 16.0) - 1.0) < 0.05
     rel = np.abs(big - small) / (np.abs(small) + 0.02)
     assert rel.mean() < 0.15 and rel.max() < 0.6, f"block means disagree: mean {rel.mean():.3f}, max {rel.max():.3f}"
+
+
+def test_ten_thousand_sphere_scene_at_full_size_rows_against_the_oracle(pkg, orc, ctx):
+    """BASELINE's last configuration at its own size: the 7680x4320 frame of the 10 000-sphere scene, four accumulated samples
+    as ONE launch of the kernel with pixel slots.  The oracle is out of reach for the whole frame (its linear scan does
+    0.3 Mrays/s), so sixteen rows spread over the frame are rendered by it, one row per thread, and compared with the launch's
+    accumulator and bytes bit for bit; the launch's ray count must equal four single frames'."""
+    from concurrent.futures import ThreadPoolExecutor
+    s = pkg.Scene("spheres10k")
+    s.desc.max_ray_bounces = 5
+    w, h, n = 7680, 4320, 4
+    ctx.load(s, w, h)
+    ctx.reset_accum()
+    ctx.render_samples_device(1, n, seed=0x5EED)
+    st = ctx.stats()
+    acc = ctx.read_accum()
+    assert st["rays_reused_camera"] >= (n - 1) * w * h and acc[..., 3].min() == float(n) == acc[..., 3].max()
+    cam = s.camera(w, h)
+    rows = [int(round(i * (h - 1) / 15.0)) for i in range(16)]
+    ref_acc = np.zeros((h, w, 4), dtype=np.float32)
+
+    def one_row(y):
+        out = None
+        for f in range(1, n + 1):
+            out = orc.render(s.desc, cam, (), frame_index=f, accumulate=True, seed=0x5EED, rows=(y, y + 1), accum=ref_acc, n_threads=1)
+        return y, out["rgba"][y].copy()
+
+    with ThreadPoolExecutor(max_workers=16) as pool:
+        ref_rows = dict(pool.map(one_row, rows))
+    for y in rows:
+        assert np.array_equal(acc[y].view(np.uint32), ref_acc[y].view(np.uint32)), f"8K row {y}: accumulator differs from the oracle"
+    # the frame's bytes: divide, clamp and pack of that accumulator (src/renderer.rs:59-75), as the launch wrote them
+    import torch
+    out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    acc_t = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    ctx.render_samples_device(1, n, seed=0x5EED, d_rgba8=out.data_ptr(), d_accum=acc_t.data_ptr())
+    rays_again = ctx.stats()["rays_total"]
+    got = out.cpu().numpy()
+    for y in rows:
+        assert np.array_equal(got[y], ref_rows[y]), f"8K row {y}: bytes differ from the oracle"
+    assert rays_again == st["rays_total"]
+    total = 0
+    acc_t.zero_()
+    for f in range(1, n + 1):
+        ctx.render_device(frame_index=f, accumulate=True, seed=0x5EED, d_rgba8=out.data_ptr(), d_accum=acc_t.data_ptr())
+        total += ctx.stats()["rays_total"]
+    assert total == st["rays_total"]
+    assert np.array_equal(acc_t.cpu().numpy().view(np.uint32), acc.view(np.uint32)), "four single frames differ from the one launch"
 
 
 def test_hierarchy_with_every_primitive_kind_shadows_textures_and_glass(pkg, orc, ctx):
