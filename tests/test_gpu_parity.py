@@ -517,6 +517,30 @@ def test_whole_4k_frame_equals_the_oracle(pkg, orc, ctx, name):
     assert_parity(rgba, ref["rgba"], acc, ref["accum"], what=f"{name} whole 4K frame")
 
 
+@pytest.mark.parametrize("seed", _fuzz_seeds(3))
+def test_benchmark_scenes_from_random_cameras_against_the_oracle(pkg, orc, ctx, seed):
+    """The four 4K benchmark scenes from random camera poses (above, below and inside the objects, looking in any direction)
+    at a random ragged size.  Every pose is set with rt_set_camera and rendered twice: the first frame computes its primary
+    directions in the render kernel, the second reads the table -- both against the oracle's frame and ray count."""
+    rng = np.random.default_rng(9100 + seed)
+    for name in ("scene3", "tex4", "scene1", "scene4"):
+        s = pkg.Scene(name)
+        if not s.desc.ray_marching:
+            s.desc.max_ray_bounces = int(rng.integers(1, 6))
+        w, h = int(rng.integers(97, 420)), int(rng.integers(61, 300))
+        ctx.load(s, w, h)
+        eye = tuple(float(v) for v in rng.uniform((-4.0, -0.3, -3.0), (4.0, 5.0, 7.0)))
+        look = rng.normal(size=3)
+        look = tuple(float(v) for v in look / np.linalg.norm(look))
+        cam = pkg.make_camera(eye, look, w, h)
+        ctx.set_camera(cam)
+        ref = orc.render(s.desc, cam, s.textures(), n_threads=16, want_counters=True)
+        for k in range(2):
+            rgba = ctx.render(frame_index=1, reset_accum=True)
+            assert_parity(rgba, ref["rgba"], ctx.read_accum(), ref["accum"], what=f"{name} seed {seed} eye {eye} look {look} frame {k}")
+            assert ctx.stats()["rays_total"] == sum(ref["counters"][:5])
+
+
 @pytest.mark.parametrize("name", ["scene3", "tex4"])
 def test_bench_configuration_at_4k_equals_the_unclassified_frame(pkg, orc, ctx, name):
     """The exact configuration bench.py times -- 3840x2160, tile classification on, RT_RENDER_SKIP_ACCUM_STORE -- against the
