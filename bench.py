@@ -390,6 +390,8 @@ def main() -> None:
             value = rays_all / elapsed_max / 1e6
             value_traced = (rays_all - sky_all) / elapsed_max / 1e6
             traffic, traffic_note = measured_traffic(workload, pkg.LIB_PATH)
+            if world > 1 and shard != "frames":   # the committed bytes are those of a launch over the whole frame on one GPU
+                traffic, traffic_note = None, "PMC traffic is measured for the one-GPU launch of this workload; a rank's launch renders a share of it"
             hinfo = ctx.hierarchy_info()
             if args.no_sky_tiles:
                 sky_tiles = "off (--no-sky-tiles)"
