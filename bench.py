@@ -69,11 +69,25 @@ N_POSES = 64   # camera poses / object states a moving workload cycles through
 def spawn_ranks(n: int) -> int:
     """Starts the N ranks of a single-node run as fresh child processes of this (GPU-free) parent and waits for them.
     Rank 0 inherits stdout, so its JSON line is this command's output.  Returns the worst exit code."""
+    import random
     import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = 0
+    for _ in range(64):   # a rendezvous port below the kernel's range for outgoing connections, which nothing grabs in between
+        cand = random.randrange(20000, 32000)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", cand))
+            port = cand
+            break
+        except OSError:
+            continue
+        finally:
+            s.close()
+    if port == 0:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),

@@ -12,6 +12,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
+    """A rendezvous port below the range the kernel hands out for outgoing connections (32768...): a port that the kernel
+    picked for this process and that was closed again can be taken as a source port by a process that is still winding down
+    before the ranks get to bind it."""
+    import random
+    for _ in range(64):
+        port = random.randrange(20000, 32000)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", port))
+            return port
+        except OSError:
+            continue
+        finally:
+            s.close()
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -189,6 +203,8 @@ def _pattern_worker(rank, world, port, out_dir):
         ok = ok and bool(torch.equal(xch.frame[:h], want))
     with open(os.path.join(out_dir, f"pattern_{rank}.txt"), "w") as fh:
         fh.write("ok" if ok else "bad")
+    dist.barrier()   # no rank closes its connections while another is still inside the last collective
+    dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [3, 4])
