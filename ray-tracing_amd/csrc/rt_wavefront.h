@@ -480,7 +480,11 @@ RT_DEV bool wf_claim_pixel(const DevCamera &C, const DevFrame &F, const WfArgs &
             if (threadIdx.x == 0u) item = atomicAdd(&W.ctrl[kWfCtrlNext], 1u);
             item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
             if (item >= n_items) { cur.exhausted = 1u; break; }
-            const uint32_t trow = item / W.tiles_x, tx = item - trow * W.tiles_x;   // tile rows top-down
+            // tile rows from the bottom of the frame up, like the Whitted kernels: the sky -- pixels whose camera ray ends the
+            // path, all samples settled at once -- comes last and fills the end of the launch (8K, 64 samples: 192.3 -> 189.9 ms;
+            // 8 samples 30.0 -> 29.5 ms)
+            const uint32_t trow_up = item / W.tiles_x, tx = item - trow_up * W.tiles_x;
+            const uint32_t trow = W.tiles_y - 1u - trow_up;
             cur.x0 = tx * kChTileW; cur.y0 = F.row_begin + trow * F.tile_row_step; cur.i = 0u; cur.n = kChTilePixels;
         }
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));

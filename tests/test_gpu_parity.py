@@ -893,6 +893,7 @@ def test_ten_thousand_sphere_scene_at_full_size_rows_against_the_oracle(pkg, orc
     import torch
     out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
     acc_t = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # (torch fills on its own stream, the context renders on its own)
     ctx.render_samples_device(1, n, seed=0x5EED, d_rgba8=out.data_ptr(), d_accum=acc_t.data_ptr())
     rays_again = ctx.stats()["rays_total"]
     got = out.cpu().numpy()
@@ -901,6 +902,7 @@ def test_ten_thousand_sphere_scene_at_full_size_rows_against_the_oracle(pkg, orc
     assert rays_again == st["rays_total"]
     total = 0
     acc_t.zero_()
+    torch.cuda.synchronize()
     for f in range(1, n + 1):
         ctx.render_device(frame_index=f, accumulate=True, seed=0x5EED, d_rgba8=out.data_ptr(), d_accum=acc_t.data_ptr())
         total += ctx.stats()["rays_total"]
