@@ -39,7 +39,7 @@ inline RtAabb rt_transform_box(const float *m, const float lo[3], const float hi
     return b;
 }
 
-// Bounds of everything an object's intersect() can report, or false for unbounded / never-hit kinds.
+// Bounds of everything an object's intersect() can report, or false for unbounded / never-hit kinds and for cones (below).
 inline bool rt_object_bounds(const rt_object &o, RtAabb &b) {
     switch (o.kind) {
         case RT_SPHERE: {  // unit sphere in object space
@@ -55,10 +55,14 @@ inline bool rt_object_bounds(const rt_object &o, RtAabb &b) {
             const float lo[3] = {-1, -1, -0.5f}, hi[3] = {1, 1, 0.5f};
             b = rt_transform_box(o.transform, lo, hi); break;
         }
-        case RT_CONE: {  // x^2 + y^2 = z^2, 0 < z <= 1
-            const float lo[3] = {-1, -1, 0}, hi[3] = {1, 1, 1};
-            b = rt_transform_box(o.transform, lo, hi); break;
-        }
+        case RT_CONE:
+            // No bounds, although the surface x^2 + y^2 = z^2, 0 < z <= 1 has some.  Cone::intersect (src/utils/cone.rs:73-152)
+            // solves a quadratic whose leading coefficient dx^2 + dy^2 - dz^2 is ~0 for every ray direction near the cone's own
+            // slope, wherever the ray is; there (-b - sqrt(disc)) / 2a is rounding noise divided by almost nothing, and when
+            // that lands between z = 0 and z = 1 the reference reports a hit -- on rays that pass nowhere near the cone (seen
+            // once in 7 * 10^8 pixels of random scenes).  Only testing every ray reproduces those, so cones are tested like
+            // planes: always.
+            return false;
         case RT_TRIANGLE:
             b.reset(); b.grow(o.v1); b.grow(o.v2); b.grow(o.v3); break;
         default:
@@ -219,7 +223,7 @@ inline void rt_bvh_build(const rt_scene_desc *d, std::vector<DevBvhNode> &nodes,
     nodes.clear(); unbounded.clear();
     for (uint32_t i = 0; i < d->n_objects; i++) {
         if (rt_object_bounds(d->objects[i], B.boxes[i])) B.ids.push_back(i);
-        else if (d->objects[i].kind == RT_PLANE) unbounded.push_back(i);
+        else if (d->objects[i].kind == RT_PLANE || d->objects[i].kind == RT_CONE) unbounded.push_back(i);
     }
     if (B.ids.empty()) return;
     B.build(0, (uint32_t)B.ids.size());
@@ -266,7 +270,7 @@ inline void rt_bvh2_build(const rt_scene_desc *d, RtBvh2 &out) {
     for (uint32_t i = 0; i < d->n_objects; i++) {
         B.kinds[i] = rt_leaf_kind(d->objects[i]);
         if (rt_object_bounds(d->objects[i], B.boxes[i])) ids.push_back(i);
-        else if (d->objects[i].kind == RT_PLANE) out.linear.push_back(i);
+        else if (d->objects[i].kind == RT_PLANE || d->objects[i].kind == RT_CONE) out.linear.push_back(i);
     }
     // outliers: while taking one object out shrinks the root box's surface at least 16-fold, take it out
     auto root_of = [&](const std::vector<uint32_t> &v, uint32_t skip) { RtAabb r; r.reset(); for (uint32_t id : v) if (id != skip) r.grow(B.boxes[id]); return r; };

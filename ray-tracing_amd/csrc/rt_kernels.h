@@ -306,12 +306,15 @@ RT_DEV int trace_closest_bvh(const DevScene &S, f3 ro, f3 rd, float &t_out, int 
     cnt.ray(ray_slot);
     float closest = RT_F32_MAX;
     int best = -1, best_sub = 0;
-    for (uint32_t k = 0; k < S.n_unbounded; k++) {  // planes: wave-uniform loop
+    for (uint32_t k = 0; k < S.n_unbounded; k++) {  // planes and cones (no usable bounds, see rt_object_bounds): wave-uniform loop
         const uint32_t idx = S.unbounded[k];
         const DevObject &o = S.objects[idx];
         float t = 0.0f;
-        cnt.add(RT_CNT_TEST_PLANE);
-        if (cand_plane(o, ro, rd, t) && t > 0.0f && (t < closest || (t == closest && (int)idx < best))) { closest = t; best = (int)idx; best_sub = 0; }
+        int sub = 0;
+        bool ok;
+        if (o.kind == RT_PLANE) { cnt.add(RT_CNT_TEST_PLANE); ok = cand_plane(o, ro, rd, t); }
+        else { cnt.add(RT_CNT_TEST_CONE); ok = cand_cone(o, ro, rd, t, sub); }
+        if (ok && t > 0.0f && (t < closest || (t == closest && (int)idx < best))) { closest = t; best = (int)idx; best_sub = sub; }
     }
     const f3 inv = 1.0f / rd;
     const int n_nodes = (int)S.n_bvh_nodes;
