@@ -236,6 +236,7 @@ def test_caller_owned_device_buffers_and_stream(pkg, ctx):
     want = ctx.render(frame_index=1, reset_accum=True)
     rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
     ctx.render_device(frame_index=1, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(rgba.cpu().numpy(), want)
@@ -284,15 +285,18 @@ def test_skipping_the_accumulator_store_changes_no_pixel(pkg, ctx, name):
     ctx.load(s, w, h)
     rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
     accum = torch.full((h, w, 4), 7.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
     ctx.render_device(frame_index=1, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), flags=pkg.RT_RENDER_SKIP_ACCUM_STORE)
     ctx.stats()
     assert bool((accum == 7.0).all()), "the accumulator was written"
     ref_rgba = torch.zeros_like(rgba)
     ref_acc = torch.zeros_like(accum)
+    torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
     ctx.render_device(frame_index=1, d_rgba8=ref_rgba.data_ptr(), d_accum=ref_acc.data_ptr())
     ctx.stats()
     assert torch.equal(rgba, ref_rgba) and not bool((ref_acc == 7.0).any())
     a = torch.zeros_like(accum); b = torch.zeros_like(accum)
+    torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
     ctx.render_device(frame_index=1, accumulate=True, d_rgba8=rgba.data_ptr(), d_accum=a.data_ptr(), flags=pkg.RT_RENDER_SKIP_ACCUM_STORE)
     ctx.render_device(frame_index=1, accumulate=True, d_rgba8=rgba.data_ptr(), d_accum=b.data_ptr())
     ctx.stats()
@@ -309,6 +313,7 @@ def test_launch_without_timing_events_renders_the_same_frame(pkg, ctx):
     rays = ctx.stats()["rays_total"]
     assert ctx.stats()["last_kernel_ms"] > 0.0
     rgba = torch.zeros((96, 160, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
     ctx.render_device(frame_index=1, d_rgba8=rgba.data_ptr(), no_timing=True)
     st = ctx.stats()
     assert st["last_kernel_ms"] == 0.0 and st["rays_total"] == rays
@@ -555,6 +560,7 @@ def test_bench_configuration_at_4k_equals_the_unclassified_frame(pkg, orc, ctx, 
     frames = {}
     for flags in (pkg.RT_RENDER_SKIP_ACCUM_STORE, pkg.RT_RENDER_SKIP_ACCUM_STORE | pkg.RT_RENDER_NO_SKY_TILES, 0):
         rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
         for _ in range(2):   # the first frame of a camera computes its directions in the kernel, the second reads the table
             ctx.render_device(frame_index=1, d_rgba8=rgba.data_ptr(), flags=flags, no_timing=True)
         st = ctx.stats()
@@ -651,6 +657,7 @@ def test_regrouping_path_tracer_equals_the_one_lane_per_pixel_kernel(pkg, ctx, n
     for flags in (0, pkg.RT_RENDER_ONE_LANE_PER_PIXEL):
         rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
         accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
         rays = []
         for f in (1, 2, 3):
             ctx.render_device(frame_index=f, accumulate=True, seed=21, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), flags=flags)
@@ -1081,6 +1088,7 @@ def test_sky_tile_classification_changes_no_pixel(pkg, orc, ctx, name, size):
         for flags in (0, pkg.RT_RENDER_NO_SKY_TILES):
             rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
             accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
             ctx.render_device(frame_index=1, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), flags=flags, **kw)
             rays = ctx.stats()["rays_total"]
             out.append((rgba.cpu().numpy(), accum.cpu().numpy(), rays))
@@ -1165,6 +1173,7 @@ def test_sky_tile_classification_on_random_scenes_and_cameras(pkg, ctx, seed):
         for flags in (0, pkg.RT_RENDER_NO_SKY_TILES):
             rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
             accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
             ctx.render_device(frame_index=1, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), flags=flags)
             rays = ctx.stats()["rays_total"]   # waits for the context's stream
             out.append((rgba.cpu().numpy(), accum.cpu().numpy(), rays))
@@ -1276,6 +1285,7 @@ def test_random_diffuse_scenes_through_the_regrouping_path_tracer(pkg, orc, ctx,
     for flags in (0, pkg.RT_RENDER_ONE_LANE_PER_PIXEL):
         rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
         accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
         rays = 0
         for f in (1, 2, 3):
             ctx.render_device(frame_index=f, accumulate=True, seed=31 + seed, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr(), flags=flags)
@@ -1294,6 +1304,7 @@ def test_random_diffuse_scenes_through_the_regrouping_path_tracer(pkg, orc, ctx,
     # oracle's five frames, bytes, accumulator and ray count (max_ray_bounces 1 ends every path at its camera ray)
     rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
     ctx.render_samples_device(1, 3, seed=31 + seed, d_rgba8=rgba.data_ptr(), d_accum=accum.data_ptr())
     st = ctx.stats()
     assert st["rays_total"] == ref_rays and 0 < st["rays_reused_camera"] <= 2 * w * h
@@ -1444,12 +1455,14 @@ def test_resolve_after_external_accumulation(pkg, orc, ctx):
     parts = []
     for shard in range(2):  # two "ranks", each with its own zeroed accumulator and interleaved sample indices
         acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
         for idx in pkg.shard_samples(6, shard, 2):
             ctx.render_device(frame_index=idx, accumulate=True, seed=0x5EED, d_accum=acc.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
         parts.append(acc)
     torch.cuda.synchronize()
     total = parts[0] + parts[1]
     rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
     ctx.resolve_device(6, d_accum=total.data_ptr(), d_rgba8=rgba.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     ref_acc = np.zeros((h, w, 4), dtype=np.float32)

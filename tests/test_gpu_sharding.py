@@ -22,10 +22,12 @@ def test_interleaved_tile_row_shares_compose_the_frame(pkg, ctx, name, size, wor
     acc = bool(s.desc.diffuse)
     full_rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
     full_acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
     ctx.render_device(frame_index=1, accumulate=acc, seed=3, d_rgba8=full_rgba.data_ptr(), d_accum=full_acc.data_ptr())
     rays = ctx.stats()["rays_total"]
     rgba = torch.zeros_like(full_rgba)
     accum = torch.zeros_like(full_acc)
+    torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
     share_rays = 0
     for rank in range(world):
         ctx.render_device(frame_index=1, accumulate=acc, seed=3, rows=(rank * 8, h), tile_row_stride=world,

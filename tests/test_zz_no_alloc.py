@@ -65,6 +65,7 @@ def test_noalloc_entry_point_equals_render_device_on_two_calls_in_a_row(pkg):
             fresh.load(s, 320, 200)
             rgba = torch.zeros((200, 320, 4), dtype=torch.uint8, device="cuda")
             accum = torch.zeros((200, 320, 4), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()   # torch fills on its own stream; the context's stream does not wait for it
             frames = []
             for noalloc in (True, False, True):
                 accum.zero_()
