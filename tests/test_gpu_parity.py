@@ -18,8 +18,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _fuzz_seeds(n):
-    """Seeds of a seeded fuzz test: 0 ... n-1, plus RT_FUZZ_EXTRA more when the variable is set (one-off longer campaigns)."""
-    return list(range(n + int(os.environ.get("RT_FUZZ_EXTRA", "0"))))
+    """Seeds of a seeded fuzz test: 0 ... n-1, plus RT_FUZZ_EXTRA more when the variable is set (one-off longer campaigns),
+    starting at RT_FUZZ_FIRST (default: n, right behind the suite's own)."""
+    extra = int(os.environ.get("RT_FUZZ_EXTRA", "0"))
+    first = int(os.environ.get("RT_FUZZ_FIRST", str(n)))
+    return list(range(n)) + list(range(max(first, n), max(first, n) + extra))
 
 
 def gpu_frame(ctx, accumulate=False, frame_index=1, seed=0x5EED, reset=True, events=False):
