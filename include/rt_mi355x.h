@@ -350,9 +350,9 @@ int32_t rt_read_ray_directions(rt_ctx *ctx, float *out_vec3, size_t n_vec3);
  * Scenes with fewer than 32 bounded objects have no hierarchy: every count is 0. */
 typedef struct rt_hierarchy_info {
     uint32_t stackless_nodes;    /* nodes of one layout of the skip-link hierarchy (one-lane-per-pixel kernels)              */
-    uint32_t stackless_linear;   /* objects outside it, tested linearly (planes)                                           */
+    uint32_t stackless_linear;   /* objects outside it, tested linearly (planes, and cones: their intersect() has no usable bounds) */
     uint32_t two_child_nodes;    /* nodes of the quantised two-child hierarchy; 0 unless the scene is diffuse without glass */
-    uint32_t two_child_linear;   /* objects outside it: planes and objects too large for its 16-bit grid                   */
+    uint32_t two_child_linear;   /* objects outside it: planes, cones and objects too large for its 16-bit grid           */
     uint32_t regrouping_kernel;  /* 1: rt_render_device traces this scene with the kernel that re-groups rays between bounces */
     uint32_t sky_workgroups;     /* last tile classification (see RT_RENDER_NO_SKY_TILES): workgroups whose tiles are all sky ... */
     uint32_t classified_workgroups; /* ... of this many workgroups of that launch; both 0 when no launch has used one          */
